@@ -1,0 +1,226 @@
+/*
+ * svr.h — C ABI of the MI355X-native replacement for the Vulkan geometry pass of
+ * imalexlee/simple-vk-renderer.
+ *
+ * Drop-in boundary: the reference has no FFI layer; the replaced path sits behind one C++ member,
+ *     void VulkanEngine::draw_geometry(VkCommandBuffer cmd);        (src/vk_engine.h:189)
+ * called once per frame from VulkanEngine::draw() (src/vk_engine.cpp:1265).  Every input of that
+ * function is an implicit member of the engine singleton, so the ABI below makes them explicit:
+ * POD mirrors of the reference structs + opaque u32 handles where the reference holds VkBuffer /
+ * VkImage / VkSampler / pointers.  Each entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - every call returns 0 on success or a negative SvrError; svr_last_error() gives the text
+ *     (the reference aborts in VK_CHECK, src/vk_types.h:23-30; nothing here aborts or throws).
+ *   - matrices are column-major float[16], exactly glm::mat4 memory layout.
+ *   - a context is single-threaded (one context <-> one host thread), like the reference engine.
+ *   - work is enqueued on the context's HIP stream and is asynchronous like a recorded
+ *     VkCommandBuffer; svr_sync / svr_read_* are the fence waits.
+ *   - handles are 1-based; 0 is never valid.
+ *
+ * Two libraries export exactly these symbols:
+ *   simple-vk-renderer_amd/csrc/libsvr_hip.so   the product (HIP, gfx950)
+ *   oracle/libsvr_oracle.so                     the CPU scalar oracle (test infrastructure only)
+ */
+#ifndef SVR_H
+#define SVR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct SvrContext SvrContext;
+typedef uint32_t SvrMesh;
+typedef uint32_t SvrImage;
+typedef uint32_t SvrSampler;
+typedef uint32_t SvrMaterial;
+
+enum SvrError {
+  SVR_OK = 0,
+  SVR_ERR_INVALID_ARGUMENT = -1,
+  SVR_ERR_OUT_OF_MEMORY = -2,
+  SVR_ERR_DEVICE = -3,      /* a HIP call failed (text in svr_last_error) */
+  SVR_ERR_BAD_HANDLE = -4,
+  SVR_ERR_UNSUPPORTED = -5,
+  SVR_ERR_OVERFLOW = -6     /* an internal per-frame buffer overflowed twice in a row */
+};
+
+/* Colour target formats.  The reference draws into VK_FORMAT_R16G16B16A16_SFLOAT
+ * (src/vk_engine.cpp:749); RGBA8 is what its blit hands the swapchain (src/vk_engine.cpp:1276). */
+enum SvrColorFormat { SVR_COLOR_RGBA16F = 0, SVR_COLOR_RGBA8 = 1 };
+
+/* MaterialPass, src/vk_types.h:127-131 */
+enum SvrMaterialPass { SVR_PASS_MAIN_COLOR = 0, SVR_PASS_TRANSPARENT = 1, SVR_PASS_OTHER = 2 };
+
+/* VkFilter / VkSamplerMipmapMode values used by src/vk_loader.cpp:26-54 */
+enum SvrFilter { SVR_FILTER_NEAREST = 0, SVR_FILTER_LINEAR = 1 };
+enum SvrMipmapMode { SVR_MIPMAP_NEAREST = 0, SVR_MIPMAP_LINEAR = 1 };
+
+/* struct Vertex, src/vk_types.h:97-103 — 48 bytes, offsets 0/12/16/28/32 */
+typedef struct SvrVertex {
+  float position[3];
+  float uv_x;
+  float normal[3];
+  float uv_y;
+  float color[4];
+} SvrVertex;
+
+/* struct GPUSceneData, src/vk_types.h:118-125 — 240 bytes */
+typedef struct SvrSceneData {
+  float view[16];
+  float proj[16];
+  float viewproj[16];
+  float ambient_color[4];
+  float sunlight_direction[4];
+  float sunlight_color[4];
+} SvrSceneData;
+
+/* struct Bounds, src/vk_loader.h:11-15 — 28 bytes */
+typedef struct SvrBounds {
+  float origin[3];
+  float sphere_radius;
+  float extents[3];
+} SvrBounds;
+
+/* struct RenderObject, src/vk_engine.h:29-38.  `mesh` stands for {index_buffer, vertex_buf_addr}
+ * (both belong to one GPUMeshBuffers), `material` for MaterialInstance*. */
+typedef struct SvrRenderObject {
+  uint32_t index_count;
+  uint32_t first_index;
+  SvrMesh mesh;
+  SvrMaterial material;
+  SvrBounds bounds;
+  float transform[16];
+} SvrRenderObject;
+
+/* VkSamplerCreateInfo fields the reference sets (src/vk_loader.cpp:197-211,
+ * src/vk_engine.cpp:252-261); address mode is always REPEAT (zero-initialised). */
+typedef struct SvrSamplerDesc {
+  int32_t mag_filter;   /* SvrFilter */
+  int32_t min_filter;   /* SvrFilter */
+  int32_t mipmap_mode;  /* SvrMipmapMode */
+  float min_lod;
+  float max_lod;        /* VK_LOD_CLAMP_NONE = 1000.0f */
+} SvrSamplerDesc;
+
+/* struct EngineStats, src/vk_engine.h:16-22, plus device-side counters of this implementation. */
+typedef struct SvrStats {
+  float frame_time;         /* not produced by this path (run() fills it) */
+  int32_t triangle_count;   /* sum index_count/3 over submitted draws, src/vk_engine.cpp:1456 */
+  int32_t drawcall_count;   /* src/vk_engine.cpp:1455 */
+  float scene_update_time;  /* not produced by this path */
+  float mesh_draw_time;     /* host ms spent inside svr_draw_geometry (CPU record time) */
+  /* extensions */
+  float gpu_time_ms;             /* device ms of the last completed pass (hipEvent) */
+  uint32_t culled_draws;         /* opaque draws rejected by is_visible */
+  uint32_t reserved0;
+  uint64_t shaded_fragments;     /* fragment-shader evaluations (no helper lanes) */
+  uint64_t rasterized_fragments; /* covered pixel-centre samples that reached the depth test */
+  uint64_t binned_triangles;     /* triangles that survived clip/cull/zero-area */
+  uint64_t bin_entries;          /* (triangle, tile) pairs */
+} SvrStats;
+
+typedef struct SvrConfig {
+  int32_t device;         /* HIP device ordinal (ignored by the oracle) */
+  uint32_t width;         /* _draw_extent, src/vk_engine.cpp:1251-1254 */
+  uint32_t height;
+  int32_t color_format;   /* SvrColorFormat */
+  uint32_t reserved[4];
+} SvrConfig;
+
+/* engine bootstrap for this path: device + _draw_image/_depth_image (src/vk_engine.cpp:743-789) */
+int svr_create(const SvrConfig* cfg, SvrContext** out);
+void svr_destroy(SvrContext* ctx);
+
+/* The HIP stream all work is enqueued on (a hipStream_t; NULL = the legacy default stream).
+ * Stands for the graphics queue + command buffer of src/vk_engine.cpp:1243-1321. */
+int svr_set_stream(SvrContext* ctx, void* hip_stream);
+
+/* Render into caller-owned device memory instead of the context's own targets (pass NULL to
+ * restore).  color: width*height*(8|4) bytes, depth: width*height*4 bytes, row-major, no padding.
+ * Stands for _draw_image / _depth_image being engine-owned VkImages (src/vk_engine.h:118-119). */
+int svr_bind_targets(SvrContext* ctx, void* color_dev, void* depth_dev);
+int svr_get_targets(SvrContext* ctx, void** color_dev, void** depth_dev);
+
+/* VulkanEngine::upload_mesh(span<u32>, span<Vertex>) -> GPUMeshBuffers  (src/vk_engine.cpp:340-390) */
+int svr_upload_mesh(SvrContext* ctx, const uint32_t* indices, size_t n_indices,
+                    const SvrVertex* vertices, size_t n_vertices, SvrMesh* out);
+int svr_destroy_mesh(SvrContext* ctx, SvrMesh mesh);
+
+/* VulkanEngine::create_image(void* data, extent, R8G8B8A8_UNORM, usage, mipmapped)
+ * (src/vk_engine.cpp:1571-1612) incl. vkutil::generate_mipmaps (src/vk_images.cpp:66-133) */
+int svr_create_image(SvrContext* ctx, const void* rgba8, uint32_t width, uint32_t height,
+                     int mipmapped, SvrImage* out);
+int svr_destroy_image(SvrContext* ctx, SvrImage image);
+/* read one mip level back (tightly packed RGBA8); w and h receive its size.  Test hook. */
+int svr_read_image_level(SvrContext* ctx, SvrImage image, uint32_t level, void* dst, size_t bytes,
+                         uint32_t* w, uint32_t* h);
+
+/* vkCreateSampler call sites: src/vk_loader.cpp:197-211, src/vk_engine.cpp:252-261 */
+int svr_create_sampler(SvrContext* ctx, const SvrSamplerDesc* desc, SvrSampler* out);
+
+/* GLTFMettallicRoughness::write_material (src/vk_engine.cpp:1690-1714) with the
+ * MaterialConstants it points at (src/vk_engine.h:52-57).  Only the colour texture is sampled by
+ * mesh.frag; metal_rough_factors are carried but unused, as in the reference shaders. */
+int svr_write_material(SvrContext* ctx, int pass, const float color_factors[4],
+                       const float metal_rough_factors[4], SvrImage color_image,
+                       SvrSampler color_sampler, SvrMaterial* out);
+
+/* Result of draw_background (src/vk_engine.cpp:1341-1355, gradient_color.comp with
+ * data1 == data2): fill the whole colour target with one RGBA value. */
+int svr_clear_color(SvrContext* ctx, const float rgba[4]);
+
+/* vkCmdSetScissor (src/vk_engine.cpp:1431-1437).  The reference always passes the full extent and
+ * so does svr_create; the multi-GPU path gives each rank its band of rows.  The viewport stays
+ * (0,0,width,height).  Pixels outside the scissor are left untouched (colour AND depth). */
+int svr_set_scissor(SvrContext* ctx, uint32_t x, uint32_t y, uint32_t w, uint32_t h);
+
+/* VulkanEngine::draw_geometry (src/vk_engine.cpp:1357-1477): cull opaque with is_visible, sort,
+ * begin rendering (colour LOAD, depth CLEAR 0.0), draw opaque then transparent with
+ * mesh.vert/mesh.frag, end.  The arrays are borrowed for the duration of the call. */
+int svr_draw_geometry(SvrContext* ctx, const SvrSceneData* scene,
+                      const SvrRenderObject* opaque, size_t n_opaque,
+                      const SvrRenderObject* transparent, size_t n_transparent,
+                      SvrStats* out_stats);
+
+/* BASELINE config 1: one render pass drawing 3 vertices with colored_triangle.vert/.frag
+ * (shaders/colored_triangle.vert:6-25, .frag:9-12) and the opaque pipeline state. */
+int svr_draw_colored_triangle(SvrContext* ctx, SvrStats* out_stats);
+
+/* BASELINE config 2: one render pass with _mesh_pipeline (src/vk_engine.cpp:1006-1051):
+ * colored_triangle_mesh.vert (gl_Position = render_matrix * pos) + tex_image.frag
+ * (outColor = texture(displayTexture, uv), alpha included). */
+int svr_draw_tex_image(SvrContext* ctx, SvrMesh mesh, uint32_t first_index, uint32_t index_count,
+                       const float render_matrix[16], SvrImage image, SvrSampler sampler,
+                       SvrStats* out_stats);
+
+/* mesh.vert as a stand-alone operator over a vertex range (shaders/mesh.vert:29-38): per vertex
+ * writes gl_Position (4 floats) to out_clip and normal.xyz,color.xyz,uv.xy (8 floats) to
+ * out_varyings, both host pointers.  Per-stage parity hook. */
+int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint32_t n_vertices,
+                      const float world[16], const SvrSceneData* scene, SvrMaterial material,
+                      float* out_clip, float* out_varyings);
+
+/* fence wait (vkWaitForFences, src/vk_engine.cpp:1226) */
+int svr_sync(SvrContext* ctx);
+
+/* Read the colour target back to host memory.  as_rgba8 != 0 converts RGBA16F texels with the
+ * identity-extent blit of src/vk_images.cpp:33-64: clamp to [0,1], *255, round-to-nearest-even,
+ * R,G,B,A byte order. */
+int svr_read_color(SvrContext* ctx, void* dst, size_t bytes, int as_rgba8);
+int svr_read_depth(SvrContext* ctx, float* dst, size_t bytes);
+
+/* counters of the last pass; waits for it to finish */
+int svr_get_stats(SvrContext* ctx, SvrStats* out);
+
+const char* svr_last_error(void);
+/* "hip-gfx950" or "cpu-oracle" */
+const char* svr_backend_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVR_H */
