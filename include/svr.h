@@ -204,6 +204,12 @@ int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint
                       const float world[16], const SvrSceneData* scene, SvrMaterial material,
                       float* out_clip, float* out_varyings);
 
+/* Implementation switches (the reference has compile-time flags only).
+ * SVR_OPT_COUNT_FRAGMENTS: 1 = count rasterized/shaded fragments and binned triangles with device
+ * atomics (instrumented kernels; keep 0 for timed runs). */
+enum SvrOption { SVR_OPT_COUNT_FRAGMENTS = 1 };
+int svr_set_option(SvrContext* ctx, int option, int64_t value);
+
 /* fence wait (vkWaitForFences, src/vk_engine.cpp:1226) */
 int svr_sync(SvrContext* ctx);
 

@@ -642,7 +642,7 @@ void raster_rows(SvrContext* ctx, const SvrSceneData* scene, const std::vector<S
         float b1, b2;
         bary_at(t, px, py, b1, b2);
         float z = fmaf(b2, t.dz2, fmaf(b1, t.dz1, t.z0));
-        z = fminf(fmaxf(z, 0.0f), 1.0f);
+        z = fminf(fmaxf(z, 0.0f), 1.0f) + 0.0f;  // + 0.0f: never store -0.0 (C5)
         size_t p = (size_t)py * W + px;
         // depth test GREATER_OR_EQUAL (src/vk_engine.cpp:1659)
         if (!(z >= ctx->depth[p])) continue;
@@ -948,10 +948,18 @@ int svr_draw_geometry(SvrContext* ctx, const SvrSceneData* scene, const SvrRende
   if (!ctx || !scene || (!opaque && n_opaque) || (!transparent && n_transparent))
     return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_geometry: null argument");
   auto t0 = std::chrono::steady_clock::now();
-  for (size_t i = 0; i < n_opaque; i++)
+  // MeshNode::Draw routes by pass_type (src/vk_engine.cpp:1729-1733): Transparent materials only in
+  // the transparent list, everything else only in the opaque list.  Anything else is rejected.
+  for (size_t i = 0; i < n_opaque; i++) {
     if (int e = validate_object(ctx, opaque[i], "opaque")) return e;
-  for (size_t i = 0; i < n_transparent; i++)
+    if (ctx->materials[opaque[i].material - 1].pass == SVR_PASS_TRANSPARENT)
+      return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_geometry: Transparent material in the opaque list");
+  }
+  for (size_t i = 0; i < n_transparent; i++) {
     if (int e = validate_object(ctx, transparent[i], "transparent")) return e;
+    if (ctx->materials[transparent[i].material - 1].pass != SVR_PASS_TRANSPARENT)
+      return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_geometry: non-Transparent material in the transparent list");
+  }
   // cull (src/vk_engine.cpp:1361-1367): opaque only
   std::vector<uint32_t> order;
   order.reserve(n_opaque);
@@ -1068,6 +1076,12 @@ int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint
     std::memcpy(out_varyings + 8 * (size_t)i, o.attr, 32);
   }
   return SVR_OK;
+}
+
+int svr_set_option(SvrContext* ctx, int option, int64_t) {
+  if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  if (option != SVR_OPT_COUNT_FRAGMENTS) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_set_option: unknown option");
+  return SVR_OK;  // the oracle always counts
 }
 
 int svr_sync(SvrContext* ctx) {

@@ -63,13 +63,14 @@ PASS_MAIN_COLOR, PASS_TRANSPARENT, PASS_OTHER = 0, 1, 2
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 MIPMAP_NEAREST, MIPMAP_LINEAR = 0, 1
 LOD_CLAMP_NONE = 1000.0
+OPT_COUNT_FRAGMENTS = 1
 
 # every symbol include/svr.h declares
 SYMBOLS = ["svr_create", "svr_destroy", "svr_set_stream", "svr_bind_targets", "svr_get_targets",
            "svr_upload_mesh", "svr_destroy_mesh", "svr_create_image", "svr_destroy_image",
            "svr_read_image_level", "svr_create_sampler", "svr_write_material", "svr_clear_color",
            "svr_set_scissor", "svr_draw_geometry", "svr_draw_colored_triangle", "svr_draw_tex_image",
-           "svr_run_mesh_vert", "svr_sync", "svr_read_color", "svr_read_depth", "svr_get_stats",
+           "svr_run_mesh_vert", "svr_set_option", "svr_sync", "svr_read_color", "svr_read_depth", "svr_get_stats",
            "svr_last_error", "svr_backend_name"]
 
 
@@ -115,6 +116,7 @@ class SvrLib:
                                          C.c_uint32, C.c_uint32, C.POINTER(SvrStats)]
         L.svr_run_mesh_vert.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
                                         C.POINTER(SvrSceneData), C.c_uint32, P, P]
+        L.svr_set_option.argtypes = [P, C.c_int, C.c_int64]
         L.svr_sync.argtypes = [P]
         L.svr_read_color.argtypes = [P, P, C.c_size_t, C.c_int]
         L.svr_read_depth.argtypes = [P, P, C.c_size_t]
@@ -262,6 +264,9 @@ class Renderer:
                                                       C.byref(scene), material, clip.ctypes.data,
                                                       var.ctypes.data))
         return clip, var
+
+    def set_option(self, option, value):
+        self.lib.check(self.lib.lib.svr_set_option(self.h, option, value))
 
     def sync(self):
         self.lib.check(self.lib.lib.svr_sync(self.h))

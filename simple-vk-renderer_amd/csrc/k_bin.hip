@@ -1,0 +1,151 @@
+// k_bin.hip — sort-middle binning of set-up triangles into 32x32-pixel screen tiles.
+//
+// The rasteriser hardware behind vkCmdDrawIndexed walks each triangle's pixels itself; here the
+// frame is cut into tiles (one workgroup each, k_tile.hip) and every triangle is appended to the
+// bin of every tile it can touch.  count -> exclusive scan -> fill, so bins are contiguous spans of
+// one buffer and no per-tile capacity exists.  Bin order is arbitrary (atomics): the tile kernel
+// is order-independent (depth+sequence-key resolve for opaque, key-ordered peeling for blended).
+// Two bin sets share the arrays: [0,n_tiles) opaque, [n_tiles,2*n_tiles) transparent.
+//
+// One lane per record; triangles touching more than 16 tiles are handed to the whole wave, which
+// walks their tile range 64 tiles at a time.  Tiles inside the bbox that no edge function can
+// reach are skipped (conservative corner test), identically in the count and fill passes.
+#include "svr_launch.h"
+
+namespace svr {
+
+constexpr int SMALL_MAX_TILES = 16;
+
+struct EdgeSet {
+  double A0, A1, A2, B0, B1, B2, C0, C1, C2;
+};
+
+__device__ __forceinline__ EdgeSet load_edges(const TriRec* rec) {
+  const double2* p = reinterpret_cast<const double2*>(rec);
+  double2 a = p[2], b = p[3], c = p[4], d = p[5];
+  EdgeSet e;
+  e.A0 = a.x; e.A1 = a.y; e.A2 = b.x; e.B0 = b.y; e.B1 = c.x; e.B2 = c.y; e.C0 = d.x; e.C1 = d.y;
+  e.C2 = rec->C[2];
+  return e;
+}
+
+// can any pixel centre of [x0,x1]x[y0,y1] be inside? (max of each edge function over the box)
+__device__ __forceinline__ bool box_overlaps(const EdgeSet& e, int x0, int y0, int x1, int y1) {
+  double fx0 = (double)x0, fx1 = (double)x1, fy0 = (double)y0, fy1 = (double)y1;
+  double m0 = fma(e.A0, e.A0 >= 0.0 ? fx1 : fx0, fma(e.B0, e.B0 >= 0.0 ? fy1 : fy0, e.C0));
+  double m1 = fma(e.A1, e.A1 >= 0.0 ? fx1 : fx0, fma(e.B1, e.B1 >= 0.0 ? fy1 : fy0, e.C1));
+  double m2 = fma(e.A2, e.A2 >= 0.0 ? fx1 : fx0, fma(e.B2, e.B2 >= 0.0 ? fy1 : fy0, e.C2));
+  return m0 >= 0.0 && m1 >= 0.0 && m2 >= 0.0;
+}
+
+template <bool FILL>
+__device__ __forceinline__ void emit(const FrameParams& P, uint32_t bin, uint32_t rec) {
+  if (!FILL) {
+    atomicAdd(&P.tile_count[bin], 1u);
+  } else {
+    uint32_t slot = atomicAdd(&P.tile_cursor[bin], 1u);
+    uint32_t pos = P.tile_offset[bin] + slot;
+    if (pos < P.bin_cap) P.bins[pos] = rec;
+  }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void bin_kernel(FrameParams P) {
+  uint32_t ovf = P.counters->overflow;
+  if (ovf & 3u) return;            // geometry overflowed: the pass is void, the host retries
+  if (FILL && ovf) return;
+  uint32_t n_rec = P.n_tris + min(P.counters->n_extra, P.extra_cap);
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  bool valid = r < n_rec;
+  int minx = 1, miny = 0, maxx = 0, maxy = 0;
+  uint32_t flags = 0;
+  if (valid) {
+    uint4 h = *reinterpret_cast<const uint4*>(P.recs + r);
+    minx = (int)(int16_t)(h.x & 0xffffu);
+    miny = (int)(int16_t)(h.x >> 16);
+    maxx = (int)(int16_t)(h.y & 0xffffu);
+    maxy = (int)(int16_t)(h.y >> 16);
+    flags = h.w;
+    valid = minx <= maxx;
+  }
+  int tx0 = (minx - (int)P.sx) >> TILE_SHIFT, tx1 = (maxx - (int)P.sx) >> TILE_SHIFT;
+  int ty0 = (miny - (int)P.sy) >> TILE_SHIFT, ty1 = (maxy - (int)P.sy) >> TILE_SHIFT;
+  int ntx = tx1 - tx0 + 1, nty = ty1 - ty0 + 1;
+  int nt = valid ? ntx * nty : 0;
+  uint32_t binbase = (flags & F_TRANSPARENT) ? P.n_tiles : 0u;
+
+  if (valid && nt <= SMALL_MAX_TILES) {
+    if (nt <= 4) {
+      for (int ty = ty0; ty <= ty1; ty++)
+        for (int tx = tx0; tx <= tx1; tx++) emit<FILL>(P, binbase + (uint32_t)ty * P.tiles_x + (uint32_t)tx, r);
+    } else {
+      EdgeSet e = load_edges(P.recs + r);
+      for (int ty = ty0; ty <= ty1; ty++)
+        for (int tx = tx0; tx <= tx1; tx++) {
+          int x0 = max(minx, (int)P.sx + tx * TILE), x1 = min(maxx, (int)P.sx + tx * TILE + TILE - 1);
+          int y0 = max(miny, (int)P.sy + ty * TILE), y1 = min(maxy, (int)P.sy + ty * TILE + TILE - 1);
+          if (box_overlaps(e, x0, y0, x1, y1)) emit<FILL>(P, binbase + (uint32_t)ty * P.tiles_x + (uint32_t)tx, r);
+        }
+    }
+  }
+  // large triangles: the wave takes them one at a time, 64 tiles per step
+  unsigned long long big = __ballot(valid && nt > SMALL_MAX_TILES);
+  uint32_t lane = threadIdx.x & 63;
+  while (big) {
+    int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    uint32_t rr = __shfl(r, src);
+    int bminx = __shfl(minx, src), bminy = __shfl(miny, src), bmaxx = __shfl(maxx, src), bmaxy = __shfl(maxy, src);
+    int btx0 = __shfl(tx0, src), bty0 = __shfl(ty0, src), bntx = __shfl(ntx, src), bnt = __shfl(nt, src);
+    uint32_t bbase = __shfl(binbase, src);
+    EdgeSet e = load_edges(P.recs + rr);  // same address in every lane: one broadcast load
+    for (int t = (int)lane; t < bnt; t += 64) {
+      int ty = bty0 + t / bntx, tx = btx0 + t % bntx;
+      int x0 = max(bminx, (int)P.sx + tx * TILE), x1 = min(bmaxx, (int)P.sx + tx * TILE + TILE - 1);
+      int y0 = max(bminy, (int)P.sy + ty * TILE), y1 = min(bmaxy, (int)P.sy + ty * TILE + TILE - 1);
+      if (box_overlaps(e, x0, y0, x1, y1)) emit<FILL>(P, bbase + (uint32_t)ty * P.tiles_x + (uint32_t)tx, rr);
+    }
+  }
+}
+
+// exclusive scan of tile_count[0 .. 2*n_tiles) by one 1024-thread workgroup
+__global__ __launch_bounds__(1024) void scan_kernel(FrameParams P) {
+  __shared__ uint32_t part[1024];
+  uint32_t n = 2u * P.n_tiles;
+  uint32_t per = (n + 1023u) / 1024u;
+  uint32_t b = threadIdx.x * per, e = min(b + per, n);
+  uint32_t sum = 0;
+  for (uint32_t i = b; i < e; i++) sum += P.tile_count[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    uint32_t v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - sum;
+  for (uint32_t i = b; i < e; i++) {
+    P.tile_offset[i] = run;
+    run += P.tile_count[i];
+  }
+  if (threadIdx.x == 1023) {
+    uint32_t total = part[1023];
+    P.counters->total_entries = total;
+    if (total > P.bin_cap) atomicOr(&P.counters->overflow, 4u);
+  }
+}
+
+static inline uint32_t bin_blocks(const FrameParams& P) { return (P.n_tris + P.extra_cap + 255u) / 256u; }
+
+void launch_bin_count(const FrameParams& P, hipStream_t s) {
+  hipLaunchKernelGGL(bin_kernel<false>, dim3(bin_blocks(P)), dim3(256), 0, s, P);
+}
+void launch_bin_scan(const FrameParams& P, hipStream_t s) {
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, P);
+}
+void launch_bin_fill(const FrameParams& P, hipStream_t s) {
+  hipLaunchKernelGGL(bin_kernel<true>, dim3(bin_blocks(P)), dim3(256), 0, s, P);
+}
+
+}  // namespace svr

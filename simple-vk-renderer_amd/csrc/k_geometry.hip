@@ -1,0 +1,202 @@
+// k_geometry.hip — vertex stage + primitive assembly + clip + triangle setup.
+//
+// Replaces, per vkCmdDrawIndexed (src/vk_engine.cpp:1453): index fetch, mesh.vert
+// (shaders/mesh.vert:29-38), clipping to the Vulkan clip volume, perspective divide, viewport
+// transform (src/vk_engine.cpp:1421-1429) and the rasteriser's triangle setup.
+//
+// One lane per triangle, one wave per 64 consecutive triangles of ONE draw (WaveChunk), so the
+// draw's matrices are wave-uniform.  The vertex shader is re-run per triangle corner instead of
+// being cached in an intermediate post-transform buffer: a 48-byte vertex gather out of L2 plus
+// ~30 fma is cheaper on this chip than a second pass that writes and re-gathers transformed
+// vertices (DESIGN.md "Geometry").  Triangles that need real clipping (any vertex beyond the
+// near/far planes or the guard band) are queued and handled by clip_kernel so this kernel keeps
+// no polygon arrays in scratch.
+#include "svr_launch.h"
+
+namespace svr {
+
+__device__ __forceinline__ void shade_corner(const DrawDesc& d, uint32_t kind, const float* mvp, uint32_t index, VOut& o) {
+  VertexRaw v = load_vertex(d.vtx, index);
+  if (kind == PIPE_MESH)
+    mesh_vert(v, mvp, d.mat, d.color_factors, o);
+  else
+    colored_triangle_mesh_vert(v, d.mat, o);
+}
+
+__global__ __launch_bounds__(256) void setup_kernel(FrameParams P) {
+  uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint32_t lane = threadIdx.x & 63;
+  if (gw >= P.n_chunks) return;
+  WaveChunk ch = P.chunks[gw];
+  const DrawDesc& d = P.draws[ch.draw];
+  uint32_t tri = ch.first_tri + lane;
+  if (tri >= d.tri_count) return;
+  uint32_t seq = d.tri_base + tri;
+  uint32_t kind = (d.flags >> F_KIND_SHIFT) & 3u;
+  TriRec* rec = P.recs + seq;
+
+  VOut v0, v1, v2;
+  if (kind == PIPE_COLORED_TRIANGLE) {
+    colored_triangle_vert(0, v0);
+    colored_triangle_vert(1, v1);
+    colored_triangle_vert(2, v2);
+  } else {
+    float mvp[16];
+    if (kind == PIPE_MESH) {
+      matmul4(P.scene.viewproj, d.mat, mvp);  // sceneData.viewproj * PushConstants.renderMatrix
+    }
+    uint32_t i0 = d.idx[3 * tri + 0], i1 = d.idx[3 * tri + 1], i2 = d.idx[3 * tri + 2];
+    shade_corner(d, kind, mvp, i0, v0);
+    shade_corner(d, kind, mvp, i1, v1);
+    shade_corner(d, kind, mvp, i2, v2);
+  }
+  int c0 = outcode(v0.clip), c1 = outcode(v1.clip), c2 = outcode(v2.clip);
+  if (c0 & c1 & c2) {
+    store_invalid(rec);
+    return;
+  }
+  float hw = (float)P.W * 0.5f, hh = (float)P.H * 0.5f;
+  if (((c0 | c1 | c2) & (OC_NEAR | OC_FAR)) == 0) {
+    ScreenV s0 = to_screen(v0.clip, hw, hh), s1 = to_screen(v1.clip, hw, hh), s2 = to_screen(v2.clip, hw, hh);
+    if (s0.ok && s1.ok && s2.ok) {
+      if (setup_triangle(P, &v0, &v1, &v2, s0, s1, s2, seq + 1, d.flags, d.tex, rec)) {
+        if (P.instrument) atomicAdd(&P.counters->binned, 1ull);
+      } else {
+        store_invalid(rec);
+      }
+      return;
+    }
+  }
+  // slow path: hand over to the clipper
+  store_invalid(rec);
+  uint32_t slot = atomicAdd(&P.counters->n_clip, 1u);
+  if (slot < P.clip_cap) {
+    ClipItem it;
+    it.draw = ch.draw;
+    it.tri = tri;
+    P.clip_queue[slot] = it;
+  } else {
+    atomicOr(&P.counters->overflow, 1u);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float plane_dist(int plane, const float* c) {
+  switch (plane) {
+    case 0: return c[3] - c[2];
+    case 1: return c[2];
+    case 2: return c[3] + c[0];
+    case 3: return c[3] - c[0];
+    case 4: return c[3] + c[1];
+    default: return c[3] - c[1];
+  }
+}
+
+// Sutherland-Hodgman against the six planes (C2); new vertices always interpolate inside -> outside.
+__device__ int clip_polygon(VOut* poly, int n) {
+  VOut tmp[12];
+  for (int plane = 0; plane < 6 && n >= 3; plane++) {
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+      const VOut& a = poly[i];
+      const VOut& b = poly[(i + 1 == n) ? 0 : i + 1];
+      float da = plane_dist(plane, a.clip), db = plane_dist(plane, b.clip);
+      bool ina = da >= 0.0f, inb = db >= 0.0f;
+      if (ina) tmp[m++] = a;
+      if (ina != inb) {
+        const VOut& pin = ina ? a : b;
+        const VOut& pout = ina ? b : a;
+        float din = ina ? da : db, dout = ina ? db : da;
+        float t = din / (din - dout);
+        VOut nv;
+        for (int k = 0; k < 4; k++) nv.clip[k] = fmaf(t, pout.clip[k] - pin.clip[k], pin.clip[k]);
+        for (int k = 0; k < 8; k++) nv.attr[k] = fmaf(t, pout.attr[k] - pin.attr[k], pin.attr[k]);
+        tmp[m++] = nv;
+      }
+    }
+    n = m;
+    for (int i = 0; i < n; i++) poly[i] = tmp[i];
+  }
+  return n >= 3 ? n : 0;
+}
+
+// One lane per queued triangle, grid-stride over the device-side queue length.
+__global__ __launch_bounds__(64) void clip_kernel(FrameParams P) {
+  uint32_t n = min(P.counters->n_clip, P.clip_cap);
+  float hw = (float)P.W * 0.5f, hh = (float)P.H * 0.5f;
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+    ClipItem it = P.clip_queue[q];
+    const DrawDesc& d = P.draws[it.draw];
+    uint32_t kind = (d.flags >> F_KIND_SHIFT) & 3u;
+    uint32_t seq = d.tri_base + it.tri;
+    VOut poly[12];
+    if (kind == PIPE_COLORED_TRIANGLE) {
+      colored_triangle_vert(0, poly[0]);
+      colored_triangle_vert(1, poly[1]);
+      colored_triangle_vert(2, poly[2]);
+    } else {
+      float mvp[16];
+      if (kind == PIPE_MESH) matmul4(P.scene.viewproj, d.mat, mvp);
+      for (int k = 0; k < 3; k++) shade_corner(d, kind, mvp, d.idx[3 * it.tri + k], poly[k]);
+    }
+    int np = clip_polygon(poly, 3);
+    for (int i = 1; i + 1 < np; i++) {
+      ScreenV s0 = to_screen(poly[0].clip, hw, hh), s1 = to_screen(poly[i].clip, hw, hh),
+              s2 = to_screen(poly[i + 1].clip, hw, hh);
+      if (!(s0.ok && s1.ok && s2.ok)) continue;
+      if (!(poly[0].clip[3] > 0.0f && poly[i].clip[3] > 0.0f && poly[i + 1].clip[3] > 0.0f)) continue;
+      TriRec tmp;
+      if (!setup_triangle(P, &poly[0], &poly[i], &poly[i + 1], s0, s1, s2, seq + 1, d.flags, d.tex, &tmp)) continue;
+      uint32_t slot = atomicAdd(&P.counters->n_extra, 1u);
+      if (slot >= P.extra_cap) {
+        atomicOr(&P.counters->overflow, 2u);
+        continue;
+      }
+      uint4* dst = reinterpret_cast<uint4*>(P.recs + P.n_tris + slot);
+      const uint4* src = reinterpret_cast<const uint4*>(&tmp);
+      for (int k = 0; k < 16; k++) dst[k] = src[k];
+      if (P.instrument) atomicAdd(&P.counters->binned, 1ull);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mesh.vert as a stand-alone operator: one vertex per lane, three coalesced 16-byte loads per lane
+// (a wave reads 3 KiB contiguous), writes gl_Position and the 8 varyings.
+__global__ __launch_bounds__(256) void mesh_vert_kernel(const SvrVertex* vtx, uint32_t first, uint32_t n,
+                                                        const float* world16, const float* viewproj16,
+                                                        const float* cf4, float* out_clip, float* out_var) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float world[16], viewproj[16], mvp[16], cf[4];
+  for (int k = 0; k < 16; k++) {
+    world[k] = world16[k];
+    viewproj[k] = viewproj16[k];
+  }
+  for (int k = 0; k < 4; k++) cf[k] = cf4[k];
+  matmul4(viewproj, world, mvp);
+  VertexRaw v = load_vertex(vtx, first + i);
+  VOut o;
+  mesh_vert(v, mvp, world, cf, o);
+  reinterpret_cast<float4*>(out_clip)[i] = make_float4(o.clip[0], o.clip[1], o.clip[2], o.clip[3]);
+  reinterpret_cast<float4*>(out_var)[2 * i] = make_float4(o.attr[0], o.attr[1], o.attr[2], o.attr[3]);
+  reinterpret_cast<float4*>(out_var)[2 * i + 1] = make_float4(o.attr[4], o.attr[5], o.attr[6], o.attr[7]);
+}
+
+void launch_setup(const FrameParams& P, hipStream_t s) {
+  if (P.n_chunks == 0) return;
+  uint32_t blocks = (P.n_chunks + 3) / 4;
+  hipLaunchKernelGGL(setup_kernel, dim3(blocks), dim3(256), 0, s, P);
+}
+void launch_clip(const FrameParams& P, hipStream_t s) {
+  hipLaunchKernelGGL(clip_kernel, dim3(512), dim3(64), 0, s, P);
+}
+void launch_mesh_vert(const SvrVertex* vtx, uint32_t first, uint32_t n, const float* world16,
+                      const float* viewproj16, const float* color_factors4, float* out_clip,
+                      float* out_varyings, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(mesh_vert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, vtx, first, n, world16, viewproj16,
+                     color_factors4, out_clip, out_varyings);
+}
+
+}  // namespace svr

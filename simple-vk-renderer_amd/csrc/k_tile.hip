@@ -1,0 +1,415 @@
+// k_tile.hip — per-tile rasterisation, depth test, fragment shading, blending and write-back.
+//
+// Replaces everything the Vulkan implementation does per fragment for the two material pipelines
+// (src/vk_engine.cpp:1619-1688): fill rasterisation at pixel centres with the top-left rule, depth
+// test GREATER_OR_EQUAL on D32 with write (opaque) or without (transparent), mesh.frag
+// (shaders/mesh.frag:12-19) / tex_image.frag / colored_triangle.frag with implicit-LOD texturing,
+// blending (src/vk_pipelines.cpp:151-167), the depth clear to 0.0 and colour LOAD/STORE
+// (src/vk_initializers.cpp:117-164).
+//
+// One 256-thread workgroup per 32x32 tile; wave w owns the 16x16 quadrant w and lane l owns four
+// pixels of it (one per 8x8 block), so depth, sequence key and winning triangle live in VGPRs and
+// never touch LDS or HBM until the single final store.  The tile's triangle bin is staged through
+// LDS in batches (coalesced 128-byte coverage halves), every wave walks the batch with wave-uniform
+// bbox rejects.  Coverage is exact: edge functions are integers < 2^53 evaluated in fp64.
+//   phase A  opaque visibility: per pixel max over (depth, submission key) == in-order GE test
+//   phase B  shade each visible pixel once (deferred: identical result, no overdraw shading)
+//   phase C  transparent fragments peeled per pixel in submission order, blended at target precision
+//   phase D  store colour where touched, depth everywhere (the CLEAR is fused here)
+#include <hip/hip_fp16.h>
+
+#include "svr_launch.h"
+
+namespace svr {
+
+constexpr int BATCH = 64;  // triangles staged per LDS batch: 64 x 128 B = 8 KiB
+
+struct CovTri {  // the coverage half as read back from LDS (wave-uniform values)
+  int minx, miny, maxx, maxy;
+  uint32_t key, flags;
+  float z0, dz1, dz2, inv_area;
+  double A0, A1, A2, B0, B1, B2, C0, C1, C2;
+};
+
+__device__ __forceinline__ CovTri read_cov(const uint4* s) {
+  CovTri t;
+  uint4 h = s[0];
+  t.minx = (int)(int16_t)(h.x & 0xffffu);
+  t.miny = (int)(int16_t)(h.x >> 16);
+  t.maxx = (int)(int16_t)(h.y & 0xffffu);
+  t.maxy = (int)(int16_t)(h.y >> 16);
+  t.key = h.z;
+  t.flags = h.w;
+  float4 z = reinterpret_cast<const float4*>(s)[1];
+  t.z0 = z.x; t.dz1 = z.y; t.dz2 = z.z; t.inv_area = z.w;
+  const double2* d = reinterpret_cast<const double2*>(s);
+  double2 a = d[2], b = d[3], c = d[4], e = d[5], f = d[6];
+  t.A0 = a.x; t.A1 = a.y; t.A2 = b.x; t.B0 = b.y; t.B1 = c.x; t.B2 = c.y; t.C0 = e.x; t.C1 = e.y; t.C2 = f.x;
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// texture unit (C8, C9)
+constexpr float kInv255 = 0x1.010102p-8f;
+constexpr float kG0 = 0x1.c51282p-2f, kG1 = -0x1.14a3a2p-2f, kG2 = 0x1.37536ap-3f, kG3 = -0x1.778474p-5f;
+
+__device__ __forceinline__ float lod_from_rho2(float rho2) {
+  if (!(rho2 >= 0x1p-100f)) return -50.0f;
+  if (!(rho2 <= 0x1p+100f)) return 50.0f;
+  uint32_t bits = f2u(rho2);
+  int e = (int)(bits >> 23) - 127;
+  float m = u2f((bits & 0x7fffffu) | 0x3f800000u);
+  float t = m - 1.0f;
+  float g = fmaf(fmaf(fmaf(kG3, t, kG2), t, kG1), t, kG0);
+  float s = t * (1.0f - t);
+  float l = fmaf(s, g, t);
+  return 0.5f * ((float)e + l);
+}
+
+__device__ __forceinline__ float4 unpack_texel(uint32_t t) {
+  return make_float4((float)(t & 0xffu) * kInv255, (float)((t >> 8) & 0xffu) * kInv255,
+                     (float)((t >> 16) & 0xffu) * kInv255, (float)(t >> 24) * kInv255);
+}
+__device__ __forceinline__ float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }
+
+__device__ __forceinline__ float4 sample_level(const TexBinding& tb, uint32_t level, uint32_t filter, float u, float v) {
+  u = (fabsf(u) < 8388608.0f) ? u : 0.0f;
+  v = (fabsf(v) < 8388608.0f) ? v : 0.0f;
+  int wl = (int)max(tb.w >> level, 1u), hl = (int)max(tb.h >> level, 1u);
+  const uint32_t* texels = reinterpret_cast<const uint32_t*>(tb.base + tb.level_offset[level]);
+  float U = (u - floorf(u)) * (float)wl;
+  float V = (v - floorf(v)) * (float)hl;
+  if (filter == SVR_FILTER_NEAREST) {
+    int i = (int)floorf(U), j = (int)floorf(V);
+    if (i >= wl) i -= wl;
+    if (j >= hl) j -= hl;
+    return unpack_texel(texels[j * wl + i]);
+  }
+  float Uh = U - 0.5f, Vh = V - 0.5f;
+  float fu = floorf(Uh), fv = floorf(Vh);
+  float alpha = Uh - fu, beta = Vh - fv;
+  int i0 = (int)fu, j0 = (int)fv;
+  int i1 = i0 + 1, j1 = j0 + 1;
+  if (i0 < 0) i0 += wl;
+  if (i1 >= wl) i1 -= wl;
+  if (j0 < 0) j0 += hl;
+  if (j1 >= hl) j1 -= hl;
+  float4 t00 = unpack_texel(texels[j0 * wl + i0]), t10 = unpack_texel(texels[j0 * wl + i1]);
+  float4 t01 = unpack_texel(texels[j1 * wl + i0]), t11 = unpack_texel(texels[j1 * wl + i1]);
+  float4 o;
+  o.x = lerpf(lerpf(t00.x, t10.x, alpha), lerpf(t01.x, t11.x, alpha), beta);
+  o.y = lerpf(lerpf(t00.y, t10.y, alpha), lerpf(t01.y, t11.y, alpha), beta);
+  o.z = lerpf(lerpf(t00.z, t10.z, alpha), lerpf(t01.z, t11.z, alpha), beta);
+  o.w = lerpf(lerpf(t00.w, t10.w, alpha), lerpf(t01.w, t11.w, alpha), beta);
+  return o;
+}
+
+__device__ __forceinline__ float4 sample_texture(const TexBinding& tb, float u, float v, float dudx, float dvdx,
+                                                 float dudy, float dvdy) {
+  float W0 = (float)tb.w, H0 = (float)tb.h;
+  float mx = dudx * W0, my = dvdx * H0;
+  float nx = dudy * W0, ny = dvdy * H0;
+  float rx2 = fmaf(mx, mx, my * my);
+  float ry2 = fmaf(nx, nx, ny * ny);
+  float rho2 = fmaxf(rx2, ry2);
+  float lambda = lod_from_rho2(rho2);
+  lambda = fminf(fmaxf(lambda, tb.min_lod), tb.max_lod);
+  uint32_t filter = (lambda <= 0.0f) ? (tb.filters & 1u) : ((tb.filters >> 1) & 1u);
+  int q = (int)tb.levels - 1;
+  if (((tb.filters >> 2) & 1u) == SVR_MIPMAP_NEAREST) {
+    int d = (int)ceilf(lambda + 0.5f) - 1;
+    d = min(max(d, 0), q);
+    return sample_level(tb, (uint32_t)d, filter, u, v);
+  }
+  float lc = fminf(fmaxf(lambda, 0.0f), (float)q);
+  float fl = floorf(lc);
+  int dhi = (int)fl;
+  float delta = lc - fl;
+  float4 hi = sample_level(tb, (uint32_t)dhi, filter, u, v);
+  if (delta == 0.0f) return hi;
+  int dlo = min(dhi + 1, q);
+  float4 lo = sample_level(tb, (uint32_t)dlo, filter, u, v);
+  return make_float4(lerpf(hi.x, lo.x, delta), lerpf(hi.y, lo.y, delta), lerpf(hi.z, lo.z, delta),
+                     lerpf(hi.w, lo.w, delta));
+}
+
+// ------------------------------------------------------------------------------------------------
+// fragment stage: run the triangle's fragment shader at pixel (px,py)  (C6, C7, C10, C11)
+__device__ __forceinline__ float interp3(float a0, float da1, float da2, float b1, float b2, float r) {
+  return fmaf(b2, da2, fmaf(b1, da1, a0)) * r;
+}
+
+__device__ float4 shade_pixel(const FrameParams& P, uint32_t rec, int px, int py) {
+  const TriRec* tr = P.recs + rec;
+  const uint4* q4 = reinterpret_cast<const uint4*>(tr);
+  const float4* f4 = reinterpret_cast<const float4*>(tr);
+  const double2* d2 = reinterpret_cast<const double2*>(tr);
+  uint32_t flags = q4[0].w;
+  float inv_area = f4[1].w;
+  double A1 = d2[2].y, B1 = d2[4].x, C1 = d2[5].y;
+  double A2 = d2[3].x, B2 = d2[4].y, C2 = d2[6].x;
+  uint32_t tex = tr->tex;
+  // unbiased edge values at the pixel and at its horizontal / vertical quad partners
+  double dx = (double)px, dy = (double)py;
+  double e1 = fma(A1, dx, fma(B1, dy, C1)) + ((flags & F_T1) ? 1.0 : 0.0);
+  double e2 = fma(A2, dx, fma(B2, dy, C2)) + ((flags & F_T2) ? 1.0 : 0.0);
+  float b1 = (float)e1 * inv_area, b2 = (float)e2 * inv_area;
+  // shading half
+  float4 s0 = f4[8], s1 = f4[9], s2 = f4[10], s3 = f4[11], s4 = f4[12], s5 = f4[13], s6 = f4[14];
+  // s0 = q0,dq1,dq2,a0[0] | s1 = a0[1..4] | s2 = a0[5..7],da1[0] | s3 = da1[1..4] | s4 = da1[5..7],da2[0]
+  // s5 = da2[1..4] | s6 = da2[5..7],pad
+  float q0 = s0.x, dq1 = s0.y, dq2 = s0.z;
+  float r = 1.0f / fmaf(b2, dq2, fmaf(b1, dq1, q0));
+  uint32_t kind = (flags >> F_KIND_SHIFT) & 3u;
+  if (kind == PIPE_COLORED_TRIANGLE) {  // shaders/colored_triangle.frag:9-12
+    float cr = interp3(s1.z, s3.z, s5.z, b1, b2, r);
+    float cg = interp3(s1.w, s3.w, s5.w, b1, b2, r);
+    float cb = interp3(s2.x, s4.x, s6.x, b1, b2, r);
+    return make_float4(cr, cg, cb, 1.0f);
+  }
+  float u = interp3(s2.y, s4.y, s6.y, b1, b2, r), v = interp3(s2.z, s4.z, s6.z, b1, b2, r);
+  double sxp = (px & 1) ? -1.0 : 1.0, syp = (py & 1) ? -1.0 : 1.0;
+  float hb1 = (float)fma(sxp, A1, e1) * inv_area, hb2 = (float)fma(sxp, A2, e2) * inv_area;
+  float vb1 = (float)fma(syp, B1, e1) * inv_area, vb2 = (float)fma(syp, B2, e2) * inv_area;
+  float hr = 1.0f / fmaf(hb2, dq2, fmaf(hb1, dq1, q0));
+  float vr = 1.0f / fmaf(vb2, dq2, fmaf(vb1, dq1, q0));
+  float uh = interp3(s2.y, s4.y, s6.y, hb1, hb2, hr), vh = interp3(s2.z, s4.z, s6.z, hb1, hb2, hr);
+  float uv_ = interp3(s2.y, s4.y, s6.y, vb1, vb2, vr), vv_ = interp3(s2.z, s4.z, s6.z, vb1, vb2, vr);
+  float dudx = (px & 1) ? (u - uh) : (uh - u);
+  float dvdx = (px & 1) ? (v - vh) : (vh - v);
+  float dudy = (py & 1) ? (u - uv_) : (uv_ - u);
+  float dvdy = (py & 1) ? (v - vv_) : (vv_ - v);
+  const TexBinding& tb = P.tex[tex];
+  float4 t = sample_texture(tb, u, v, dudx, dvdx, dudy, dvdy);
+  if (kind == PIPE_TEX_IMAGE) return t;  // shaders/tex_image.frag:10-12
+  // shaders/mesh.frag:12-19
+  float nx = interp3(s0.w, s2.w, s4.w, b1, b2, r);
+  float ny = interp3(s1.x, s3.x, s5.x, b1, b2, r);
+  float nz = interp3(s1.y, s3.y, s5.y, b1, b2, r);
+  const float* L = P.scene.sunlight_direction;
+  float d = fmaf(nz, L[2], fmaf(ny, L[1], nx * L[0]));
+  float light = fmaxf(d, 0.1f);
+  float sunw = P.scene.sunlight_color[3];
+  float cr = interp3(s1.z, s3.z, s5.z, b1, b2, r) * t.x;
+  float cg = interp3(s1.w, s3.w, s5.w, b1, b2, r) * t.y;
+  float cb = interp3(s2.x, s4.x, s6.x, b1, b2, r) * t.z;
+  float4 o;
+  o.x = fmaf(cr * light, sunw, cr * P.scene.ambient_color[0]);
+  o.y = fmaf(cg * light, sunw, cg * P.scene.ambient_color[1]);
+  o.z = fmaf(cb * light, sunw, cb * P.scene.ambient_color[2]);
+  o.w = 1.0f;
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// colour target codecs: the attachment holds fp16 (reference) or unorm8
+template <int FMT>
+struct Codec;
+template <>
+struct Codec<SVR_COLOR_RGBA16F> {
+  typedef uint2 enc_t;
+  static __device__ __forceinline__ enc_t encode(float4 c) {
+    uint32_t r = __half_as_ushort(__float2half_rn(c.x)), g = __half_as_ushort(__float2half_rn(c.y));
+    uint32_t b = __half_as_ushort(__float2half_rn(c.z)), a = __half_as_ushort(__float2half_rn(c.w));
+    return make_uint2(r | (g << 16), b | (a << 16));
+  }
+  static __device__ __forceinline__ float4 decode(enc_t e) {
+    return make_float4(__half2float(__ushort_as_half((unsigned short)(e.x & 0xffffu))),
+                       __half2float(__ushort_as_half((unsigned short)(e.x >> 16))),
+                       __half2float(__ushort_as_half((unsigned short)(e.y & 0xffffu))),
+                       __half2float(__ushort_as_half((unsigned short)(e.y >> 16))));
+  }
+};
+template <>
+struct Codec<SVR_COLOR_RGBA8> {
+  typedef uint32_t enc_t;
+  static __device__ __forceinline__ uint32_t un8(float f) {
+    return (uint32_t)__float2int_rn(fminf(fmaxf(f, 0.0f), 1.0f) * 255.0f);
+  }
+  static __device__ __forceinline__ enc_t encode(float4 c) {
+    return un8(c.x) | (un8(c.y) << 8) | (un8(c.z) << 16) | (un8(c.w) << 24);
+  }
+  static __device__ __forceinline__ float4 decode(enc_t e) { return unpack_texel(e); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Walk one bin (staged through LDS) and update the per-pixel state.
+//   PEEL == false: keep the fragment with the largest (depth, key)            (opaque visibility)
+//   PEEL == true : keep the depth-passing fragment with the smallest key > last   (next layer)
+template <bool PEEL, bool INSTR>
+__device__ __forceinline__ void walk_bin(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, uint32_t bin_base,
+                                         uint32_t n, int ox, int oy, int lx, int ly, const bool (&pix_ok)[4],
+                                         uint32_t (&zbits)[4], uint32_t (&keys)[4], uint32_t (&recs)[4],
+                                         const uint32_t (&last)[4], bool count_now, uint32_t& n_raster) {
+  const double dpx = (double)(ox + lx), dpy = (double)(oy + ly);
+  for (uint32_t b0 = 0; b0 < n; b0 += BATCH) {
+    uint32_t cnt = min((uint32_t)BATCH, n - b0);
+    __syncthreads();  // previous batch fully consumed
+    for (uint32_t piece = threadIdx.x; piece < cnt * 8u; piece += 256u) {
+      uint32_t ri = P.bins[bin_base + b0 + (piece >> 3)];
+      s_cov[piece] = reinterpret_cast<const uint4*>(P.recs + ri)[piece & 7u];
+      if ((piece & 7u) == 0) s_idx[piece >> 3] = ri;
+    }
+    __syncthreads();
+    for (uint32_t i = 0; i < cnt; i++) {
+      CovTri t = read_cov(s_cov + i * 8u);
+      if (t.maxx < ox || t.minx > ox + 15 || t.maxy < oy || t.miny > oy + 15) continue;  // wave-uniform
+      uint32_t ri = s_idx[i];
+      double e0 = fma(t.A0, dpx, fma(t.B0, dpy, t.C0));
+      double e1 = fma(t.A1, dpx, fma(t.B1, dpy, t.C1));
+      double e2 = fma(t.A2, dpx, fma(t.B2, dpy, t.C2));
+      double u1 = (t.flags & F_T1) ? 1.0 : 0.0, u2 = (t.flags & F_T2) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int bx = ox + (k & 1) * 8, by = oy + (k >> 1) * 8;
+        if (t.maxx < bx || t.minx > bx + 7 || t.maxy < by || t.miny > by + 7) continue;  // wave-uniform
+        double kx = (double)((k & 1) * 8), ky = (double)((k >> 1) * 8);
+        double f0 = fma(t.A0, kx, fma(t.B0, ky, e0));
+        double f1 = fma(t.A1, kx, fma(t.B1, ky, e1));
+        double f2 = fma(t.A2, kx, fma(t.B2, ky, e2));
+        bool inside = pix_ok[k] && f0 >= 0.0 && f1 >= 0.0 && f2 >= 0.0;
+        if (INSTR && count_now) n_raster += inside ? 1u : 0u;
+        float b1 = (float)(f1 + u1) * t.inv_area, b2 = (float)(f2 + u2) * t.inv_area;
+        float z = fmaf(b2, t.dz2, fmaf(b1, t.dz1, t.z0));
+        z = fminf(fmaxf(z, 0.0f), 1.0f) + 0.0f;
+        uint32_t zb = f2u(z);
+        if (!PEEL) {
+          bool better = inside && (zb > zbits[k] || (zb == zbits[k] && t.key > keys[k]));
+          if (better) {
+            zbits[k] = zb;
+            keys[k] = t.key;
+            recs[k] = ri;
+          }
+        } else {
+          bool take = inside && zb >= zbits[k] && t.key > last[k] && t.key < keys[k];
+          if (take) {
+            keys[k] = t.key;
+            recs[k] = ri;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int FMT, bool INSTR>
+__global__ __launch_bounds__(256) void tile_kernel(FrameParams P) {
+  typedef Codec<FMT> CD;
+  typedef typename CD::enc_t enc_t;
+  __shared__ uint4 s_cov[BATCH * 8];
+  __shared__ uint32_t s_idx[BATCH];
+
+  if (P.counters->overflow) return;  // pass is void; the host grows its buffers and replays it
+  // XCD-aware mapping: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), give each XCD one
+  // contiguous span of tiles so its L2 keeps that screen region's records and texels.
+  uint32_t per = (P.n_tiles + 7u) >> 3;
+  uint32_t tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+  if (tile >= P.n_tiles) return;
+  uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+  uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  int ox = (int)(P.sx + tx * TILE + (wave & 1u) * 16u), oy = (int)(P.sy + ty * TILE + (wave >> 1) * 16u);
+  int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
+  int x_end = (int)(P.sx + P.sw), y_end = (int)(P.sy + P.sh);
+
+  bool pix_ok[4];
+  uint32_t zbits[4], keys[4], recs[4], zero4[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
+    pix_ok[k] = px < x_end && py < y_end;
+    zbits[k] = 0u;  // depth CLEAR 0.0
+    keys[k] = 0u;
+    recs[k] = NO_REC;
+    zero4[k] = 0u;
+  }
+  uint32_t n_raster = 0, n_shaded = 0;
+
+  // ---- phase A: opaque visibility
+  uint32_t n_op = P.tile_count[tile], n_tr = P.tile_count[P.n_tiles + tile];
+  if (n_op) walk_bin<false, INSTR>(P, s_cov, s_idx, P.tile_offset[tile], n_op, ox, oy, lx, ly, pix_ok, zbits, keys, recs, zero4, true, n_raster);
+
+  // ---- phase B: shade visible pixels once
+  enc_t enc[4];
+  bool dirty[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    dirty[k] = recs[k] != NO_REC;
+    enc[k] = enc_t();
+    if (dirty[k]) {
+      int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
+      enc[k] = CD::encode(shade_pixel(P, recs[k], px, py));
+      if (INSTR) n_shaded++;
+    }
+  }
+
+  // ---- phase C: transparent layers in submission order
+  if (n_tr) {
+    uint32_t last[4] = {0u, 0u, 0u, 0u};
+    bool first = true;
+    for (;;) {
+      uint32_t ck[4], cr[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        ck[k] = 0xffffffffu;
+        cr[k] = NO_REC;
+      }
+      walk_bin<true, INSTR>(P, s_cov, s_idx, P.tile_offset[P.n_tiles + tile], n_tr, ox, oy, lx, ly, pix_ok, zbits, ck, cr, last, first, n_raster);
+      first = false;
+      int any = (cr[0] != NO_REC) || (cr[1] != NO_REC) || (cr[2] != NO_REC) || (cr[3] != NO_REC);
+      if (!__syncthreads_or(any)) break;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (cr[k] == NO_REC) continue;
+        int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
+        size_t p = (size_t)py * P.W + (size_t)px;
+        if (!dirty[k]) enc[k] = reinterpret_cast<const enc_t*>(P.color)[p];  // colour loadOp LOAD
+        float4 dst = CD::decode(enc[k]);
+        float4 src = shade_pixel(P, cr[k], px, py);
+        if (INSTR) n_shaded++;
+        // enable_blending_additive: rgb = src*ONE + dst*DST_ALPHA, a = src*ONE + dst*ZERO
+        float4 o = make_float4(fmaf(dst.x, dst.w, src.x), fmaf(dst.y, dst.w, src.y), fmaf(dst.z, dst.w, src.z), src.w);
+        enc[k] = CD::encode(o);
+        dirty[k] = true;
+        last[k] = ck[k];
+      }
+    }
+  }
+
+  // ---- phase D: write back
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (!pix_ok[k]) continue;
+    int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
+    size_t p = (size_t)py * P.W + (size_t)px;
+    P.depth[p] = u2f(zbits[k]);
+    if (dirty[k]) reinterpret_cast<enc_t*>(P.color)[p] = enc[k];
+  }
+  if (INSTR) {
+    for (int off = 32; off > 0; off >>= 1) {
+      n_raster += __shfl_down(n_raster, off);
+      n_shaded += __shfl_down(n_shaded, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&P.counters->rasterized, (unsigned long long)n_raster);
+      atomicAdd(&P.counters->shaded, (unsigned long long)n_shaded);
+    }
+  }
+}
+
+void launch_tiles(const FrameParams& P, int color_format, bool count_fragments, hipStream_t s) {
+  uint32_t per = (P.n_tiles + 7u) >> 3;
+  dim3 grid(per * 8u), block(256);
+  if (color_format == SVR_COLOR_RGBA16F) {
+    if (count_fragments)
+      hipLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA16F, true>), grid, block, 0, s, P);
+    else
+      hipLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA16F, false>), grid, block, 0, s, P);
+  } else {
+    if (count_fragments)
+      hipLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA8, true>), grid, block, 0, s, P);
+    else
+      hipLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA8, false>), grid, block, 0, s, P);
+  }
+}
+
+}  // namespace svr

@@ -1,0 +1,878 @@
+// svr_api.hip — the C ABI of include/svr.h over the HIP kernels (host code; no kernels here).
+//
+// Host half of VulkanEngine::draw_geometry (src/vk_engine.cpp:1357-1477): is_visible cull, sort,
+// per-draw records (the push constants + bound buffers of the record lambda, :1412-1457), then one
+// stream-ordered pass:  memset counters -> setup -> clip -> bin count -> scan -> bin fill -> tiles.
+// The pass is asynchronous like a recorded command buffer; svr_sync / readbacks are the fence.
+// Per-frame device buffers only grow.  A pass whose internal queues overflowed writes nothing to
+// the targets (every later kernel checks the flag); it is replayed with larger buffers at the next
+// fence, so results never depend on the initial capacities.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "svr_launch.h"
+
+using namespace svr;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return fail(e_ == hipErrorOutOfMemory ? SVR_ERR_OUT_OF_MEMORY : SVR_ERR_DEVICE,                  \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                                  \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {  // contents are NOT preserved
+    if (bytes <= cap) return SVR_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4;
+    HIPCHK(hipMalloc(&p, want));
+    cap = want;
+    return SVR_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct MeshRes {
+  SvrVertex* vtx = nullptr;
+  uint32_t* idx = nullptr;
+  size_t n_vtx = 0, n_idx = 0;
+  bool alive = false;
+};
+struct ImageRes {
+  uint8_t* base = nullptr;
+  uint32_t w = 0, h = 0, levels = 0;
+  uint32_t off[16] = {0};
+  bool alive = false;
+};
+struct MaterialRes {
+  int pass;
+  float cf[4], mr[4];
+  uint32_t image, sampler;  // 0-based
+};
+
+// software fp32 -> fp16 (RTE) for the one clear colour the host encodes
+uint16_t host_f32_to_f16(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  uint32_t sign = (x >> 16) & 0x8000u, ax = x & 0x7fffffffu;
+  if (ax >= 0x7f800000u) return (uint16_t)(sign | (ax > 0x7f800000u ? 0x7e00u : 0x7c00u));
+  if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+  if (ax >= 0x38800000u) {
+    uint32_t mant = ax & 0x7fffffu, h = (((ax >> 23) - 112) << 10) | (mant >> 13), rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+  }
+  if (ax < 0x33000000u) return (uint16_t)sign;
+  uint32_t mant = (ax & 0x7fffffu) | 0x800000u;
+  int shift = 126 - (int)(ax >> 23);
+  uint32_t h = mant >> shift, rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (h & 1u))) h++;
+  return (uint16_t)(sign | h);
+}
+
+}  // namespace
+
+struct SvrContext {
+  int device = 0;
+  uint32_t W = 0, H = 0;
+  int fmt = SVR_COLOR_RGBA16F;
+  hipStream_t stream = nullptr;
+  void* color_own = nullptr;
+  float* depth_own = nullptr;
+  void* color = nullptr;
+  float* depth = nullptr;
+  uint32_t sx = 0, sy = 0, sw = 0, sh = 0;
+
+  std::vector<MeshRes> meshes;
+  std::vector<ImageRes> images;
+  std::vector<SvrSamplerDesc> samplers;
+  std::vector<MaterialRes> materials;
+  DevBuf tex_table;  // TexBinding[materials + 1]; last slot = scratch binding of svr_draw_tex_image
+  size_t tex_slots = 0;
+
+  // per-pass device buffers
+  DevBuf d_draws, d_chunks, d_recs, d_clipq, d_tiles, d_bins, d_counters, d_cvt;
+  uint32_t clip_cap = 0, extra_cap = 0, bin_cap = 0;
+  // pinned host staging (ring) + readback
+  static const int RING = 3;
+  void* h_stage[RING] = {nullptr, nullptr, nullptr};
+  size_t h_stage_cap[RING] = {0, 0, 0};
+  hipEvent_t h_stage_ev[RING] = {nullptr, nullptr, nullptr};
+  bool h_stage_used[RING] = {false, false, false};
+  int ring_pos = 0;
+  Counters* h_counters = nullptr;
+
+  hipEvent_t ev_start = nullptr, ev_end = nullptr;
+  bool pending = false;      // a pass has been enqueued and not validated yet
+  FrameParams last{};        // parameters of that pass, for replay
+  bool instrument = false;
+  SvrStats stats{};
+};
+
+namespace {
+
+int use_device(SvrContext* ctx) {
+  HIPCHK(hipSetDevice(ctx->device));
+  return SVR_OK;
+}
+
+MeshRes* get_mesh(SvrContext* ctx, SvrMesh h) {
+  if (h == 0 || h > ctx->meshes.size() || !ctx->meshes[h - 1].alive) return nullptr;
+  return &ctx->meshes[h - 1];
+}
+ImageRes* get_image(SvrContext* ctx, SvrImage h) {
+  if (h == 0 || h > ctx->images.size() || !ctx->images[h - 1].alive) return nullptr;
+  return &ctx->images[h - 1];
+}
+
+TexBinding make_binding(const ImageRes& im, const SvrSamplerDesc& s) {
+  TexBinding tb;
+  std::memset(&tb, 0, sizeof(tb));
+  tb.base = im.base;
+  tb.w = im.w;
+  tb.h = im.h;
+  tb.levels = im.levels;
+  tb.filters = (uint32_t)s.mag_filter | ((uint32_t)s.min_filter << 1) | ((uint32_t)s.mipmap_mode << 2);
+  tb.min_lod = s.min_lod;
+  tb.max_lod = s.max_lod;
+  for (int l = 0; l < 16; l++) tb.level_offset[l] = im.off[l];
+  return tb;
+}
+
+// (re)upload the binding table: one slot per material + one scratch slot
+int upload_tex_table(SvrContext* ctx, const TexBinding* scratch) {
+  size_t n = ctx->materials.size() + 1;
+  std::vector<TexBinding> host(n);
+  for (size_t i = 0; i < ctx->materials.size(); i++) {
+    const MaterialRes& m = ctx->materials[i];
+    host[i] = make_binding(ctx->images[m.image], ctx->samplers[m.sampler]);
+  }
+  if (scratch)
+    host[n - 1] = *scratch;
+  else
+    std::memset(&host[n - 1], 0, sizeof(TexBinding));
+  if (ctx->tex_table.cap < n * sizeof(TexBinding)) {
+    // the table may be referenced by an in-flight pass: drain before replacing it
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (int e = ctx->tex_table.ensure(n * sizeof(TexBinding) * 2)) return e;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->tex_table.p, host.data(), n * sizeof(TexBinding), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // host vector dies here
+  ctx->tex_slots = n;
+  return SVR_OK;
+}
+
+// ---------------------------------------------------------------- is_visible, src/vk_engine.cpp:56-86
+// glm 0.9.9 scalar operation order (glm is an unpinned submodule of the reference), no fma.
+void glm_matmul(const float* a, const float* b, float* out) {
+  for (int j = 0; j < 4; j++)
+    for (int r = 0; r < 4; r++) {
+      float acc = a[0 + r] * b[4 * j + 0];
+      acc = acc + a[4 + r] * b[4 * j + 1];
+      acc = acc + a[8 + r] * b[4 * j + 2];
+      acc = acc + a[12 + r] * b[4 * j + 3];
+      out[4 * j + r] = acc;
+    }
+}
+bool is_visible(const SvrRenderObject& obj, const float* viewproj) {
+  static const float corners[8][3] = {{1, 1, 1},  {1, 1, -1},  {1, -1, 1},  {1, -1, -1},
+                                      {-1, 1, 1}, {-1, 1, -1}, {-1, -1, 1}, {-1, -1, -1}};
+  float m[16];
+  glm_matmul(viewproj, obj.transform, m);
+  float mn[3] = {1.5f, 1.5f, 1.5f}, mx[3] = {-1.5f, -1.5f, -1.5f};
+  for (int c = 0; c < 8; c++) {
+    float p[3];
+    for (int k = 0; k < 3; k++) p[k] = obj.bounds.origin[k] + corners[c][k] * obj.bounds.extents[k];
+    float v[4];
+    for (int r = 0; r < 4; r++) {
+      float add0 = m[0 + r] * p[0] + m[4 + r] * p[1];
+      float add1 = m[8 + r] * p[2] + m[12 + r] * 1.0f;
+      v[r] = add0 + add1;
+    }
+    v[0] = v[0] / v[3];
+    v[1] = v[1] / v[3];
+    v[2] = v[2] / v[3];
+    for (int k = 0; k < 3; k++) {
+      mn[k] = (mn[k] < v[k]) ? mn[k] : v[k];
+      mx[k] = (v[k] < mx[k]) ? mx[k] : v[k];
+    }
+  }
+  return !(mn[2] > 1.f || mx[2] < 0.f || mn[0] > 1.f || mx[0] < -1.f || mn[1] > 1.f || mx[1] < -1.f);
+}
+
+// ---------------------------------------------------------------- pass machinery
+int stage_slot(SvrContext* ctx, size_t bytes, void** out, int* slot_out) {
+  int s = ctx->ring_pos;
+  ctx->ring_pos = (ctx->ring_pos + 1) % SvrContext::RING;
+  if (ctx->h_stage_used[s]) HIPCHK(hipEventSynchronize(ctx->h_stage_ev[s]));
+  if (ctx->h_stage_cap[s] < bytes) {
+    if (ctx->h_stage[s]) (void)hipHostFree(ctx->h_stage[s]);
+    ctx->h_stage[s] = nullptr;
+    ctx->h_stage_cap[s] = 0;
+    size_t want = bytes + bytes / 2 + 4096;
+    HIPCHK(hipHostMalloc(&ctx->h_stage[s], want, hipHostMallocDefault));
+    ctx->h_stage_cap[s] = want;
+  }
+  *out = ctx->h_stage[s];
+  *slot_out = s;
+  return SVR_OK;
+}
+
+int enqueue_pass(SvrContext* ctx, const FrameParams& P) {
+  hipStream_t s = ctx->stream;
+  HIPCHK(hipMemsetAsync(P.counters, 0, sizeof(Counters), s));
+  // tile_count and tile_cursor are adjacent: one memset
+  HIPCHK(hipMemsetAsync(P.tile_count, 0, (size_t)P.n_tiles * 2 * sizeof(uint32_t), s));
+  HIPCHK(hipMemsetAsync(P.tile_cursor, 0, (size_t)P.n_tiles * 2 * sizeof(uint32_t), s));
+  HIPCHK(hipEventRecord(ctx->ev_start, s));
+  launch_setup(P, s);
+  launch_clip(P, s);
+  launch_bin_count(P, s);
+  launch_bin_scan(P, s);
+  launch_bin_fill(P, s);
+  launch_tiles(P, ctx->fmt, P.instrument != 0, s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev_end, s));
+  HIPCHK(hipMemcpyAsync(ctx->h_counters, P.counters, sizeof(Counters), hipMemcpyDeviceToHost, s));
+  ctx->pending = true;
+  ctx->last = P;
+  return SVR_OK;
+}
+
+// size the per-pass buffers for P.n_tris and the current capacities, fill the pointers
+int bind_pass_buffers(SvrContext* ctx, FrameParams& P) {
+  if (int e = ctx->d_recs.ensure(((size_t)P.n_tris + ctx->extra_cap) * sizeof(TriRec))) return e;
+  if (int e = ctx->d_clipq.ensure((size_t)ctx->clip_cap * sizeof(ClipItem))) return e;
+  if (int e = ctx->d_tiles.ensure((size_t)P.n_tiles * 6 * sizeof(uint32_t))) return e;
+  if (int e = ctx->d_bins.ensure((size_t)ctx->bin_cap * sizeof(uint32_t))) return e;
+  if (int e = ctx->d_counters.ensure(sizeof(Counters))) return e;
+  P.recs = (TriRec*)ctx->d_recs.p;
+  P.extra_cap = ctx->extra_cap;
+  P.clip_queue = (ClipItem*)ctx->d_clipq.p;
+  P.clip_cap = ctx->clip_cap;
+  P.tile_count = (uint32_t*)ctx->d_tiles.p;
+  P.tile_cursor = P.tile_count + (size_t)P.n_tiles * 2;
+  P.tile_offset = P.tile_count + (size_t)P.n_tiles * 4;
+  P.bins = (uint32_t*)ctx->d_bins.p;
+  P.bin_cap = ctx->bin_cap;
+  P.counters = (Counters*)ctx->d_counters.p;
+  return SVR_OK;
+}
+
+// Wait for the pending pass; if one of its queues overflowed, grow and replay it.
+int finish_pending(SvrContext* ctx) {
+  if (!ctx->pending) return SVR_OK;
+  for (int attempt = 0; attempt < 12; attempt++) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    Counters c = *ctx->h_counters;
+    if (c.overflow == 0) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_end) == hipSuccess) ctx->stats.gpu_time_ms = ms;
+      ctx->stats.bin_entries = c.total_entries;
+      if (ctx->last.instrument) {
+        ctx->stats.rasterized_fragments = c.rasterized;
+        ctx->stats.shaded_fragments = c.shaded;
+        ctx->stats.binned_triangles = c.binned;
+      }
+      ctx->pending = false;
+      return SVR_OK;
+    }
+    // buffers can be replaced: the stream is idle
+    if (c.overflow & 1u) ctx->clip_cap = std::max<uint32_t>(ctx->clip_cap * 2u, c.n_clip + 1024u);
+    if (c.overflow & 2u) ctx->extra_cap = std::max<uint32_t>(ctx->extra_cap * 2u, c.n_extra + 1024u);
+    if (c.overflow & 4u) ctx->bin_cap = std::max<uint32_t>(ctx->bin_cap * 2u, c.total_entries + c.total_entries / 4u);
+    FrameParams P = ctx->last;
+    if (int e = bind_pass_buffers(ctx, P)) return e;
+    if (int e = enqueue_pass(ctx, P)) return e;
+  }
+  ctx->pending = false;
+  return fail(SVR_ERR_OVERFLOW, "a pass kept overflowing its internal queues after 12 replays");
+}
+
+// non-blocking: validate the previous pass if it has already completed
+int poll_pending(SvrContext* ctx) {
+  if (!ctx->pending) return SVR_OK;
+  if (hipEventQuery(ctx->ev_end) == hipSuccess) return finish_pending(ctx);
+  return SVR_OK;
+}
+
+int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& draws) {
+  if (int e = poll_pending(ctx)) return e;
+  // sequence numbers + wave chunks
+  uint64_t n_tris64 = 0;
+  size_t n_chunks = 0;
+  for (DrawDesc& d : draws) {
+    d.tri_base = (uint32_t)n_tris64;
+    n_tris64 += d.tri_count;
+    n_chunks += (d.tri_count + 63u) / 64u;
+  }
+  if (n_tris64 >= 0xfffffff0ull) return fail(SVR_ERR_UNSUPPORTED, "more than 2^32 triangles in one pass");
+  FrameParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.color = ctx->color;
+  P.depth = ctx->depth;
+  P.W = ctx->W;
+  P.H = ctx->H;
+  P.sx = ctx->sx;
+  P.sy = ctx->sy;
+  P.sw = ctx->sw;
+  P.sh = ctx->sh;
+  P.tiles_x = (ctx->sw + TILE - 1) / TILE;
+  P.tiles_y = (ctx->sh + TILE - 1) / TILE;
+  P.n_tiles = P.tiles_x * P.tiles_y;
+  P.n_tris = (uint32_t)n_tris64;
+  P.n_chunks = (uint32_t)n_chunks;
+  P.tex = (const TexBinding*)ctx->tex_table.p;
+  P.instrument = ctx->instrument ? 1u : 0u;
+  if (scene) P.scene = *scene;
+  // capacities: generous first guesses; overflow -> replay (finish_pending)
+  ctx->clip_cap = std::max<uint32_t>(ctx->clip_cap, std::max<uint32_t>(65536u, P.n_tris / 4u));
+  ctx->extra_cap = std::max<uint32_t>(ctx->extra_cap, std::max<uint32_t>(65536u, P.n_tris / 2u));
+  ctx->bin_cap = std::max<uint32_t>(ctx->bin_cap, std::max<uint32_t>(1u << 24, P.n_tris * 8u));
+  // per-pass inputs: draws + chunks through pinned staging
+  size_t draw_bytes = draws.size() * sizeof(DrawDesc), chunk_bytes = n_chunks * sizeof(WaveChunk);
+  if (int e = ctx->d_draws.ensure(std::max<size_t>(draw_bytes, 256))) return e;
+  if (int e = ctx->d_chunks.ensure(std::max<size_t>(chunk_bytes, 256))) return e;
+  if (int e = bind_pass_buffers(ctx, P)) return e;
+  void* stage = nullptr;
+  int slot = 0;
+  if (int e = stage_slot(ctx, draw_bytes + chunk_bytes + 64, &stage, &slot)) return e;
+  std::memcpy(stage, draws.data(), draw_bytes);
+  WaveChunk* ch = reinterpret_cast<WaveChunk*>((char*)stage + draw_bytes);
+  size_t ci = 0;
+  for (size_t di = 0; di < draws.size(); di++)
+    for (uint32_t t = 0; t < draws[di].tri_count; t += 64u) {
+      ch[ci].draw = (uint32_t)di;
+      ch[ci].first_tri = t;
+      ci++;
+    }
+  if (draw_bytes) HIPCHK(hipMemcpyAsync(ctx->d_draws.p, stage, draw_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (chunk_bytes)
+    HIPCHK(hipMemcpyAsync(ctx->d_chunks.p, (char*)stage + draw_bytes, chunk_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->h_stage_ev[slot], ctx->stream));
+  ctx->h_stage_used[slot] = true;
+  P.draws = (const DrawDesc*)ctx->d_draws.p;
+  P.chunks = (const WaveChunk*)ctx->d_chunks.p;
+  return enqueue_pass(ctx, P);
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* svr_last_error(void) { return g_err.c_str(); }
+const char* svr_backend_name(void) { return "hip-gfx950"; }
+
+int svr_create(const SvrConfig* cfg, SvrContext** out) {
+  if (!cfg || !out) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_create: null argument");
+  if (cfg->width == 0 || cfg->height == 0 || cfg->width > 16384 || cfg->height > 16384)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_create: extent must be in 1..16384");
+  if (cfg->color_format != SVR_COLOR_RGBA16F && cfg->color_format != SVR_COLOR_RGBA8)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_create: unknown colour format");
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess || n_dev <= 0)
+    return fail(SVR_ERR_DEVICE, std::string("svr_create: no HIP device (") + hipGetErrorString(e) +
+                                    "); this library has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= n_dev) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_create: bad device ordinal");
+  HIPCHK(hipSetDevice(cfg->device));
+  SvrContext* ctx = new SvrContext();
+  ctx->device = cfg->device;
+  ctx->W = cfg->width;
+  ctx->H = cfg->height;
+  ctx->fmt = cfg->color_format;
+  ctx->sw = ctx->W;
+  ctx->sh = ctx->H;
+  size_t n = (size_t)ctx->W * ctx->H;
+  size_t cbytes = n * (ctx->fmt == SVR_COLOR_RGBA16F ? 8 : 4);
+  auto bail = [&](hipError_t err, const char* what) {
+    std::string msg = std::string(what) + ": " + hipGetErrorString(err);
+    svr_destroy(ctx);
+    return fail(err == hipErrorOutOfMemory ? SVR_ERR_OUT_OF_MEMORY : SVR_ERR_DEVICE, msg);
+  };
+  hipError_t r;
+  if ((r = hipMalloc(&ctx->color_own, cbytes)) != hipSuccess) return bail(r, "hipMalloc(color)");
+  if ((r = hipMalloc((void**)&ctx->depth_own, n * 4)) != hipSuccess) return bail(r, "hipMalloc(depth)");
+  if ((r = hipMemset(ctx->color_own, 0, cbytes)) != hipSuccess) return bail(r, "hipMemset(color)");
+  if ((r = hipMemset(ctx->depth_own, 0, n * 4)) != hipSuccess) return bail(r, "hipMemset(depth)");
+  ctx->color = ctx->color_own;
+  ctx->depth = ctx->depth_own;
+  if ((r = hipEventCreate(&ctx->ev_start)) != hipSuccess) return bail(r, "hipEventCreate");
+  if ((r = hipEventCreate(&ctx->ev_end)) != hipSuccess) return bail(r, "hipEventCreate");
+  for (int i = 0; i < SvrContext::RING; i++)
+    if ((r = hipEventCreateWithFlags(&ctx->h_stage_ev[i], hipEventDisableTiming)) != hipSuccess) return bail(r, "hipEventCreate");
+  if ((r = hipHostMalloc((void**)&ctx->h_counters, sizeof(Counters), hipHostMallocDefault)) != hipSuccess)
+    return bail(r, "hipHostMalloc");
+  *out = ctx;
+  return SVR_OK;
+}
+
+void svr_destroy(SvrContext* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& m : ctx->meshes) {
+    if (m.vtx) (void)hipFree(m.vtx);
+    if (m.idx) (void)hipFree(m.idx);
+  }
+  for (auto& im : ctx->images)
+    if (im.base) (void)hipFree(im.base);
+  DevBuf* bufs[] = {&ctx->tex_table, &ctx->d_draws, &ctx->d_chunks, &ctx->d_recs, &ctx->d_clipq,
+                    &ctx->d_tiles,   &ctx->d_bins,  &ctx->d_counters, &ctx->d_cvt};
+  for (DevBuf* b : bufs) b->release();
+  for (int i = 0; i < SvrContext::RING; i++) {
+    if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
+    if (ctx->h_stage_ev[i]) (void)hipEventDestroy(ctx->h_stage_ev[i]);
+  }
+  if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+  if (ctx->color_own) (void)hipFree(ctx->color_own);
+  if (ctx->depth_own) (void)hipFree(ctx->depth_own);
+  delete ctx;
+}
+
+int svr_set_stream(SvrContext* ctx, void* hip_stream) {
+  if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  if (int e = use_device(ctx)) return e;
+  if (int e = finish_pending(ctx)) return e;  // work on the old stream must not be orphaned
+  ctx->stream = (hipStream_t)hip_stream;
+  return SVR_OK;
+}
+
+int svr_bind_targets(SvrContext* ctx, void* color_dev, void* depth_dev) {
+  if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  if ((color_dev == nullptr) != (depth_dev == nullptr))
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_bind_targets: pass both targets or both NULL");
+  if (int e = use_device(ctx)) return e;
+  if (int e = finish_pending(ctx)) return e;
+  ctx->color = color_dev ? color_dev : ctx->color_own;
+  ctx->depth = depth_dev ? (float*)depth_dev : ctx->depth_own;
+  return SVR_OK;
+}
+
+int svr_get_targets(SvrContext* ctx, void** color_dev, void** depth_dev) {
+  if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  if (color_dev) *color_dev = ctx->color;
+  if (depth_dev) *depth_dev = ctx->depth;
+  return SVR_OK;
+}
+
+int svr_upload_mesh(SvrContext* ctx, const uint32_t* indices, size_t n_indices, const SvrVertex* vertices,
+                    size_t n_vertices, SvrMesh* out) {
+  if (!ctx || !out || (!indices && n_indices) || (!vertices && n_vertices))
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_upload_mesh: null argument");
+  if (n_vertices > 0xffffffffull || n_indices > 0xffffffffull)
+    return fail(SVR_ERR_UNSUPPORTED, "svr_upload_mesh: more than 2^32 elements");
+  for (size_t i = 0; i < n_indices; i++)
+    if (indices[i] >= n_vertices) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_upload_mesh: index out of range");
+  if (int e = use_device(ctx)) return e;
+  MeshRes m;
+  // device-local vertex + index buffers, blocking staged copy (src/vk_engine.cpp:345-381)
+  HIPCHK(hipMalloc((void**)&m.vtx, std::max<size_t>(n_vertices * sizeof(SvrVertex), 64)));
+  hipError_t r = hipMalloc((void**)&m.idx, std::max<size_t>(n_indices * 4, 64));
+  if (r != hipSuccess) {
+    (void)hipFree(m.vtx);
+    return fail(SVR_ERR_OUT_OF_MEMORY, std::string("hipMalloc(indices): ") + hipGetErrorString(r));
+  }
+  if (n_vertices) HIPCHK(hipMemcpy(m.vtx, vertices, n_vertices * sizeof(SvrVertex), hipMemcpyHostToDevice));
+  if (n_indices) HIPCHK(hipMemcpy(m.idx, indices, n_indices * 4, hipMemcpyHostToDevice));
+  m.n_vtx = n_vertices;
+  m.n_idx = n_indices;
+  m.alive = true;
+  ctx->meshes.push_back(m);
+  *out = (SvrMesh)ctx->meshes.size();
+  return SVR_OK;
+}
+
+int svr_destroy_mesh(SvrContext* ctx, SvrMesh mesh) {
+  MeshRes* m = ctx ? get_mesh(ctx, mesh) : nullptr;
+  if (!m) return fail(SVR_ERR_BAD_HANDLE, "svr_destroy_mesh: bad handle");
+  if (int e = use_device(ctx)) return e;
+  if (int e = finish_pending(ctx)) return e;
+  (void)hipFree(m->vtx);
+  (void)hipFree(m->idx);
+  m->vtx = nullptr;
+  m->idx = nullptr;
+  m->alive = false;
+  return SVR_OK;
+}
+
+int svr_create_image(SvrContext* ctx, const void* rgba8, uint32_t width, uint32_t height, int mipmapped,
+                     SvrImage* out) {
+  if (!ctx || !rgba8 || !out) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_create_image: null argument");
+  if (width == 0 || height == 0 || width > 16384 || height > 16384)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_create_image: extent must be in 1..16384");
+  if (int e = use_device(ctx)) return e;
+  ImageRes im;
+  im.w = width;
+  im.h = height;
+  im.levels = 1;
+  if (mipmapped) {  // src/vk_engine.cpp:1543-1545
+    uint32_t m = std::max(width, height);
+    while (m > 1) {
+      m >>= 1;
+      im.levels++;
+    }
+  }
+  size_t total = 0;
+  uint32_t lw = width, lh = height;
+  for (uint32_t l = 0; l < im.levels; l++) {
+    im.off[l] = (uint32_t)total;
+    total += ((size_t)lw * lh * 4 + 255) & ~(size_t)255;
+    lw = std::max(1u, lw >> 1);
+    lh = std::max(1u, lh >> 1);
+  }
+  if (total > 0xffffffffull) return fail(SVR_ERR_UNSUPPORTED, "svr_create_image: image larger than 4 GiB");
+  HIPCHK(hipMalloc((void**)&im.base, total));
+  hipError_t r = hipMemcpy(im.base, rgba8, (size_t)width * height * 4, hipMemcpyHostToDevice);
+  if (r != hipSuccess) {
+    (void)hipFree(im.base);
+    return fail(SVR_ERR_DEVICE, std::string("hipMemcpy(image): ") + hipGetErrorString(r));
+  }
+  // generate_mipmaps: level n -> n+1, each a 2:1 linear blit (src/vk_images.cpp:66-133)
+  lw = width;
+  lh = height;
+  for (uint32_t l = 1; l < im.levels; l++) {
+    uint32_t dw = std::max(1u, lw >> 1), dh = std::max(1u, lh >> 1);
+    launch_downsample(im.base + im.off[l - 1], lw, lh, im.base + im.off[l], dw, dh, ctx->stream);
+    lw = dw;
+    lh = dh;
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // immediate_submit is blocking (src/vk_engine.cpp:1110-1129)
+  im.alive = true;
+  ctx->images.push_back(im);
+  *out = (SvrImage)ctx->images.size();
+  return SVR_OK;
+}
+
+int svr_destroy_image(SvrContext* ctx, SvrImage image) {
+  ImageRes* im = ctx ? get_image(ctx, image) : nullptr;
+  if (!im) return fail(SVR_ERR_BAD_HANDLE, "svr_destroy_image: bad handle");
+  if (int e = use_device(ctx)) return e;
+  if (int e = finish_pending(ctx)) return e;
+  (void)hipFree(im->base);
+  im->base = nullptr;
+  im->alive = false;
+  return SVR_OK;
+}
+
+int svr_read_image_level(SvrContext* ctx, SvrImage image, uint32_t level, void* dst, size_t bytes, uint32_t* w,
+                         uint32_t* h) {
+  ImageRes* im = ctx ? get_image(ctx, image) : nullptr;
+  if (!im) return fail(SVR_ERR_BAD_HANDLE, "svr_read_image_level: bad handle");
+  if (level >= im->levels) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_read_image_level: no such level");
+  uint32_t lw = std::max(1u, im->w >> level), lh = std::max(1u, im->h >> level);
+  if (w) *w = lw;
+  if (h) *h = lh;
+  if (dst) {
+    size_t need = (size_t)lw * lh * 4;
+    if (bytes < need) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_read_image_level: buffer too small");
+    if (int e = use_device(ctx)) return e;
+    HIPCHK(hipMemcpy(dst, im->base + im->off[level], need, hipMemcpyDeviceToHost));
+  }
+  return SVR_OK;
+}
+
+int svr_create_sampler(SvrContext* ctx, const SvrSamplerDesc* desc, SvrSampler* out) {
+  if (!ctx || !desc || !out) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_create_sampler: null argument");
+  if ((desc->mag_filter | 1) != 1 || (desc->min_filter | 1) != 1 || (desc->mipmap_mode | 1) != 1)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_create_sampler: bad filter enum");
+  if (!(desc->min_lod <= desc->max_lod)) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_create_sampler: min_lod > max_lod");
+  ctx->samplers.push_back(*desc);
+  *out = (SvrSampler)ctx->samplers.size();
+  return SVR_OK;
+}
+
+int svr_write_material(SvrContext* ctx, int pass, const float color_factors[4], const float metal_rough_factors[4],
+                       SvrImage color_image, SvrSampler color_sampler, SvrMaterial* out) {
+  if (!ctx || !color_factors || !out) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_write_material: null argument");
+  if (!get_image(ctx, color_image)) return fail(SVR_ERR_BAD_HANDLE, "svr_write_material: bad image");
+  if (color_sampler == 0 || color_sampler > ctx->samplers.size())
+    return fail(SVR_ERR_BAD_HANDLE, "svr_write_material: bad sampler");
+  if (pass < 0 || pass > 2) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_write_material: bad pass");
+  if (int e = use_device(ctx)) return e;
+  MaterialRes m;
+  m.pass = pass;
+  for (int i = 0; i < 4; i++) {
+    m.cf[i] = color_factors[i];
+    m.mr[i] = metal_rough_factors ? metal_rough_factors[i] : 0.0f;
+  }
+  m.image = color_image - 1;
+  m.sampler = color_sampler - 1;
+  ctx->materials.push_back(m);
+  ctx->tex_slots = 0;  // table is stale; rebuilt lazily at the next draw
+  *out = (SvrMaterial)ctx->materials.size();
+  return SVR_OK;
+}
+
+int svr_clear_color(SvrContext* ctx, const float rgba[4]) {
+  if (!ctx || !rgba) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_clear_color: null argument");
+  if (int e = use_device(ctx)) return e;
+  if (int e = poll_pending(ctx)) return e;
+  uint64_t packed;
+  if (ctx->fmt == SVR_COLOR_RGBA16F) {
+    packed = (uint64_t)host_f32_to_f16(rgba[0]) | ((uint64_t)host_f32_to_f16(rgba[1]) << 16) |
+             ((uint64_t)host_f32_to_f16(rgba[2]) << 32) | ((uint64_t)host_f32_to_f16(rgba[3]) << 48);
+  } else {
+    packed = 0;
+    for (int k = 0; k < 4; k++) {
+      float c = rgba[k];
+      if (!(c == c)) c = 0.0f;
+      c = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
+      packed |= (uint64_t)(uint32_t)std::nearbyintf(c * 255.0f) << (8 * k);
+    }
+  }
+  launch_fill_color(ctx->color, ctx->W * ctx->H, ctx->fmt, packed, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return SVR_OK;
+}
+
+int svr_set_scissor(SvrContext* ctx, uint32_t x, uint32_t y, uint32_t w, uint32_t h) {
+  if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  if (w == 0 || h == 0 || (uint64_t)x + w > ctx->W || (uint64_t)y + h > ctx->H)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_set_scissor: rectangle outside the target");
+  ctx->sx = x;
+  ctx->sy = y;
+  ctx->sw = w;
+  ctx->sh = h;
+  return SVR_OK;
+}
+
+static int validate_object(SvrContext* ctx, const SvrRenderObject& o, bool transparent_list) {
+  const char* which = transparent_list ? "transparent" : "opaque";
+  MeshRes* m = get_mesh(ctx, o.mesh);
+  if (!m) return fail(SVR_ERR_BAD_HANDLE, std::string("svr_draw_geometry: bad mesh handle in ") + which);
+  if (o.material == 0 || o.material > ctx->materials.size())
+    return fail(SVR_ERR_BAD_HANDLE, std::string("svr_draw_geometry: bad material handle in ") + which);
+  if ((uint64_t)o.first_index + o.index_count > m->n_idx)
+    return fail(SVR_ERR_INVALID_ARGUMENT, std::string("svr_draw_geometry: index range outside the mesh in ") + which);
+  // MeshNode::Draw routes by pass_type (src/vk_engine.cpp:1729-1733)
+  bool is_tr = ctx->materials[o.material - 1].pass == SVR_PASS_TRANSPARENT;
+  if (is_tr && !transparent_list)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_geometry: Transparent material in the opaque list");
+  if (!is_tr && transparent_list)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_geometry: non-Transparent material in the transparent list");
+  return SVR_OK;
+}
+
+int svr_draw_geometry(SvrContext* ctx, const SvrSceneData* scene, const SvrRenderObject* opaque, size_t n_opaque,
+                      const SvrRenderObject* transparent, size_t n_transparent, SvrStats* out_stats) {
+  if (!ctx || !scene || (!opaque && n_opaque) || (!transparent && n_transparent))
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_geometry: null argument");
+  auto t0 = std::chrono::steady_clock::now();
+  if (int e = use_device(ctx)) return e;
+  for (size_t i = 0; i < n_opaque; i++)
+    if (int e = validate_object(ctx, opaque[i], false)) return e;
+  for (size_t i = 0; i < n_transparent; i++)
+    if (int e = validate_object(ctx, transparent[i], true)) return e;
+  if (ctx->tex_slots != ctx->materials.size() + 1)
+    if (int e = upload_tex_table(ctx, nullptr)) return e;
+  // cull: opaque only (src/vk_engine.cpp:1361-1367)
+  std::vector<uint32_t> order;
+  order.reserve(n_opaque);
+  for (size_t i = 0; i < n_opaque; i++)
+    if (is_visible(opaque[i], scene->viewproj)) order.push_back((uint32_t)i);
+  // sort (src/vk_engine.cpp:1369-1378): deterministic key (material, mesh, submission index)
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t ia, uint32_t ib) {
+    const SvrRenderObject& a = opaque[ia];
+    const SvrRenderObject& b = opaque[ib];
+    if (a.material == b.material) return a.mesh < b.mesh;
+    return a.material < b.material;
+  });
+  std::vector<DrawDesc> draws;
+  draws.reserve(order.size() + n_transparent);
+  SvrStats st{};
+  auto push = [&](const SvrRenderObject& o) {
+    const MeshRes& m = ctx->meshes[o.mesh - 1];
+    const MaterialRes& mat = ctx->materials[o.material - 1];
+    DrawDesc d;
+    std::memset(&d, 0, sizeof(d));
+    std::memcpy(d.mat, o.transform, 64);
+    std::memcpy(d.color_factors, mat.cf, 16);
+    d.vtx = m.vtx;
+    d.idx = m.idx + o.first_index;
+    d.tri_count = o.index_count / 3;
+    d.tex = o.material - 1;
+    d.flags = ((uint32_t)PIPE_MESH << F_KIND_SHIFT) | (mat.pass == SVR_PASS_TRANSPARENT ? F_TRANSPARENT : 0u);
+    draws.push_back(d);
+    st.drawcall_count++;
+    st.triangle_count += (int)(o.index_count / 3);
+  };
+  for (uint32_t i : order) push(opaque[i]);
+  for (size_t i = 0; i < n_transparent; i++) push(transparent[i]);
+  st.culled_draws = (uint32_t)(n_opaque - order.size());
+  int e = run_pass(ctx, scene, draws);
+  auto t1 = std::chrono::steady_clock::now();
+  st.mesh_draw_time = std::chrono::duration<float, std::milli>(t1 - t0).count();
+  ctx->stats = st;
+  if (out_stats) *out_stats = st;
+  return e;
+}
+
+int svr_draw_colored_triangle(SvrContext* ctx, SvrStats* out_stats) {
+  if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  if (int e = use_device(ctx)) return e;
+  if (ctx->tex_slots != ctx->materials.size() + 1)
+    if (int e = upload_tex_table(ctx, nullptr)) return e;
+  std::vector<DrawDesc> draws(1);
+  std::memset(&draws[0], 0, sizeof(DrawDesc));
+  draws[0].tri_count = 1;
+  draws[0].flags = (uint32_t)PIPE_COLORED_TRIANGLE << F_KIND_SHIFT;
+  SvrStats st{};
+  st.drawcall_count = 1;
+  st.triangle_count = 1;
+  int e = run_pass(ctx, nullptr, draws);
+  ctx->stats = st;
+  if (out_stats) *out_stats = st;
+  return e;
+}
+
+int svr_draw_tex_image(SvrContext* ctx, SvrMesh mesh, uint32_t first_index, uint32_t index_count,
+                       const float render_matrix[16], SvrImage image, SvrSampler sampler, SvrStats* out_stats) {
+  if (!ctx || !render_matrix) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_tex_image: null argument");
+  MeshRes* m = get_mesh(ctx, mesh);
+  if (!m) return fail(SVR_ERR_BAD_HANDLE, "svr_draw_tex_image: bad mesh");
+  ImageRes* im = get_image(ctx, image);
+  if (!im) return fail(SVR_ERR_BAD_HANDLE, "svr_draw_tex_image: bad image");
+  if (sampler == 0 || sampler > ctx->samplers.size()) return fail(SVR_ERR_BAD_HANDLE, "svr_draw_tex_image: bad sampler");
+  if ((uint64_t)first_index + index_count > m->n_idx)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_tex_image: index range outside the mesh");
+  if (int e = use_device(ctx)) return e;
+  if (int e = finish_pending(ctx)) return e;  // the scratch binding slot is about to change
+  TexBinding tb = make_binding(*im, ctx->samplers[sampler - 1]);
+  if (int e = upload_tex_table(ctx, &tb)) return e;
+  ctx->tex_slots = 0;  // scratch slot is in use: rebuild before the next mesh pass
+  std::vector<DrawDesc> draws(1);
+  DrawDesc& d = draws[0];
+  std::memset(&d, 0, sizeof(d));
+  std::memcpy(d.mat, render_matrix, 64);
+  d.vtx = m->vtx;
+  d.idx = m->idx + first_index;
+  d.tri_count = index_count / 3;
+  d.tex = (uint32_t)ctx->materials.size();
+  d.flags = (uint32_t)PIPE_TEX_IMAGE << F_KIND_SHIFT;
+  SvrStats st{};
+  st.drawcall_count = 1;
+  st.triangle_count = (int)(index_count / 3);
+  int e = run_pass(ctx, nullptr, draws);
+  ctx->stats = st;
+  if (out_stats) *out_stats = st;
+  return e;
+}
+
+int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint32_t n_vertices, const float world[16],
+                      const SvrSceneData* scene, SvrMaterial material, float* out_clip, float* out_varyings) {
+  if (!ctx || !world || !scene || !out_clip || !out_varyings)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_run_mesh_vert: null argument");
+  MeshRes* m = get_mesh(ctx, mesh);
+  if (!m) return fail(SVR_ERR_BAD_HANDLE, "svr_run_mesh_vert: bad mesh");
+  if (material == 0 || material > ctx->materials.size()) return fail(SVR_ERR_BAD_HANDLE, "svr_run_mesh_vert: bad material");
+  if ((uint64_t)first_vertex + n_vertices > m->n_vtx)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_run_mesh_vert: vertex range outside the mesh");
+  if (n_vertices == 0) return SVR_OK;
+  if (int e = use_device(ctx)) return e;
+  float consts[36];
+  std::memcpy(consts, world, 64);
+  std::memcpy(consts + 16, scene->viewproj, 64);
+  std::memcpy(consts + 32, ctx->materials[material - 1].cf, 16);
+  float* d_consts = nullptr;
+  float* d_out = nullptr;
+  HIPCHK(hipMalloc((void**)&d_consts, sizeof(consts)));
+  hipError_t r = hipMalloc((void**)&d_out, (size_t)n_vertices * 12 * sizeof(float));
+  if (r != hipSuccess) {
+    (void)hipFree(d_consts);
+    return fail(SVR_ERR_OUT_OF_MEMORY, "svr_run_mesh_vert: hipMalloc failed");
+  }
+  int rc = SVR_OK;
+  do {
+    if (hipMemcpy(d_consts, consts, sizeof(consts), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(SVR_ERR_DEVICE, "hipMemcpy"); break; }
+    float* d_clip = d_out;
+    float* d_var = d_out + (size_t)n_vertices * 4;
+    launch_mesh_vert(m->vtx, first_vertex, n_vertices, d_consts, d_consts + 16, d_consts + 32, d_clip, d_var, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail(SVR_ERR_DEVICE, "mesh_vert kernel failed"); break; }
+    if (hipMemcpy(out_clip, d_clip, (size_t)n_vertices * 16, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(SVR_ERR_DEVICE, "hipMemcpy"); break; }
+    if (hipMemcpy(out_varyings, d_var, (size_t)n_vertices * 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(SVR_ERR_DEVICE, "hipMemcpy"); break; }
+  } while (0);
+  (void)hipFree(d_consts);
+  (void)hipFree(d_out);
+  return rc;
+}
+
+int svr_set_option(SvrContext* ctx, int option, int64_t value) {
+  if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  if (option != SVR_OPT_COUNT_FRAGMENTS) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_set_option: unknown option");
+  ctx->instrument = value != 0;
+  return SVR_OK;
+}
+
+int svr_sync(SvrContext* ctx) {
+  if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  if (int e = use_device(ctx)) return e;
+  if (int e = finish_pending(ctx)) return e;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
+}
+
+int svr_read_color(SvrContext* ctx, void* dst, size_t bytes, int as_rgba8) {
+  if (!ctx || !dst) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_read_color: null argument");
+  if (int e = svr_sync(ctx)) return e;
+  size_t n = (size_t)ctx->W * ctx->H;
+  if (ctx->fmt == SVR_COLOR_RGBA8 || !as_rgba8) {
+    size_t need = n * (ctx->fmt == SVR_COLOR_RGBA8 ? 4 : 8);
+    if (bytes < need) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_read_color: buffer too small");
+    HIPCHK(hipMemcpy(dst, ctx->color, need, hipMemcpyDeviceToHost));
+    return SVR_OK;
+  }
+  if (bytes < n * 4) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_read_color: buffer too small");
+  if (int e = ctx->d_cvt.ensure(n * 4)) return e;
+  launch_rgba16f_to_rgba8(ctx->color, ctx->d_cvt.p, (uint32_t)n, ctx->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(dst, ctx->d_cvt.p, n * 4, hipMemcpyDeviceToHost));
+  return SVR_OK;
+}
+
+int svr_read_depth(SvrContext* ctx, float* dst, size_t bytes) {
+  if (!ctx || !dst) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_read_depth: null argument");
+  if (int e = svr_sync(ctx)) return e;
+  size_t n = (size_t)ctx->W * ctx->H;
+  if (bytes < n * 4) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_read_depth: buffer too small");
+  HIPCHK(hipMemcpy(dst, ctx->depth, n * 4, hipMemcpyDeviceToHost));
+  return SVR_OK;
+}
+
+int svr_get_stats(SvrContext* ctx, SvrStats* out) {
+  if (!ctx || !out) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_get_stats: null argument");
+  if (int e = svr_sync(ctx)) return e;
+  *out = ctx->stats;
+  return SVR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,327 @@
+// svr_device.h — device-side data layout and the arithmetic contract as
+// __device__ functions, shared by the geometry / binning / tile kernels.  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/svr.h"
+
+namespace svr {
+
+constexpr int TILE = 32;           // tile edge in pixels; one 256-thread workgroup per tile
+constexpr int TILE_SHIFT = 5;
+constexpr int WAVE = 64;
+constexpr float GUARD = 16384.0f;  // guard band in pixels (C3)
+constexpr uint32_t NO_REC = 0xffffffffu;
+
+enum PipelineKind : uint32_t { PIPE_MESH = 0, PIPE_COLORED_TRIANGLE = 1, PIPE_TEX_IMAGE = 2 };
+
+// flags of DrawDesc / TriRec
+constexpr uint32_t F_T1 = 1u;            // edge 1 is not top-left (biased by -1)
+constexpr uint32_t F_T2 = 2u;            // edge 2 is not top-left
+constexpr uint32_t F_KIND_SHIFT = 4;     // 2 bits
+constexpr uint32_t F_TRANSPARENT = 256u;
+
+// One draw call (RenderObject after cull+sort), 128 bytes.
+struct DrawDesc {
+  float mat[16];            // MESH: world matrix (push constant); TEX_IMAGE: render_matrix
+  float color_factors[4];   // materialData.color_factors
+  const SvrVertex* vtx;     // vertex_buf_address
+  const uint32_t* idx;      // index buffer + first_index
+  uint32_t tri_count;
+  uint32_t tri_base;        // sequence number of the draw's first triangle (submission order)
+  uint32_t tex;             // TexBinding index
+  uint32_t flags;           // kind << F_KIND_SHIFT | F_TRANSPARENT
+  uint32_t pad[4];
+};
+static_assert(sizeof(DrawDesc) == 128, "DrawDesc layout");
+
+// 64 consecutive triangles of one draw: the unit of work of one wave of the setup kernel.
+struct WaveChunk {
+  uint32_t draw;
+  uint32_t first_tri;
+};
+
+// Texture + sampler as the fragment stage sees them (combined image sampler), 128 bytes.
+struct TexBinding {
+  const uint8_t* base;      // RGBA8 texels, all mip levels, level l at base + level_offset[l]
+  uint32_t w, h, levels;
+  uint32_t filters;         // mag | min << 1 | mipmap_mode << 2
+  float min_lod, max_lod;
+  uint32_t level_offset[16];
+  uint32_t pad[8];
+};
+static_assert(sizeof(TexBinding) == 128, "TexBinding layout");
+
+// A set-up triangle, 256 bytes: first half is all the coverage/depth loop reads, second half only
+// the winners' shading reads.  Edge functions are evaluated at integer pixel indices (px,py):
+// e_i = A[i]*px + B[i]*py + C[i]  (C already carries the top-left bias); everything is an exact
+// integer < 2^53 held in a double.
+struct TriRec {
+  int16_t minx, miny, maxx, maxy;  // inclusive pixel bbox clamped to the scissor; minx>maxx = invalid
+  uint32_t key;                    // submission sequence number + 1
+  uint32_t flags;
+  float z0, dz1, dz2, inv_area;
+  double A[3], B[3], C[3];
+  uint32_t tex;
+  float zmax;
+  uint32_t pad1[4];
+  // ---- shading half
+  float q0, dq1, dq2;              // 1/w
+  float a0[8], da1[8], da2[8];     // varyings pre-divided by w: normal.xyz, color.rgb, uv
+  float pad2[5];
+};
+static_assert(sizeof(TriRec) == 256, "TriRec layout");
+static_assert(offsetof(TriRec, A) == 32 && offsetof(TriRec, q0) == 128, "TriRec layout");
+
+struct ClipItem {
+  uint32_t draw;
+  uint32_t tri;
+};
+
+// device-side frame counters (zeroed by a memset node at the head of every pass)
+struct Counters {
+  uint32_t n_clip;         // triangles queued for the clipper
+  uint32_t n_extra;        // records appended by the clipper
+  uint32_t total_entries;  // bin entries (written by the scan)
+  uint32_t overflow;       // bit0: clip queue, bit1: extra records, bit2: bin entries
+  unsigned long long rasterized;
+  unsigned long long shaded;
+  unsigned long long binned;
+  unsigned long long pad;
+};
+
+struct FrameParams {
+  // targets
+  void* color;
+  float* depth;
+  uint32_t W, H;                  // target extent == viewport
+  uint32_t sx, sy, sw, sh;        // scissor
+  uint32_t tiles_x, tiles_y, n_tiles;
+  // geometry
+  const DrawDesc* draws;
+  const WaveChunk* chunks;
+  uint32_t n_chunks;
+  uint32_t n_tris;                // main record slots
+  TriRec* recs;                   // [n_tris + extra_cap]
+  uint32_t extra_cap;
+  ClipItem* clip_queue;
+  uint32_t clip_cap;
+  // bins
+  uint32_t* tile_count;           // [2*n_tiles]: opaque bins then transparent bins
+  uint32_t* tile_offset;          // [2*n_tiles]
+  uint32_t* tile_cursor;          // [2*n_tiles]
+  uint32_t* bins;
+  uint32_t bin_cap;
+  Counters* counters;
+  const TexBinding* tex;
+  uint32_t instrument;            // count fragments/triangles with device atomics (not in timed runs)
+  uint32_t pad_;
+  SvrSceneData scene;
+};
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+
+// post-vertex-shader vertex: gl_Position + 8 varying floats
+struct VOut {
+  float clip[4];
+  float attr[8];
+};
+
+// C0/C1: column-major mat4 * vec4 as an fma chain over columns
+__device__ __forceinline__ void matvec4(const float* m, float x, float y, float z, float w, float* out) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    float acc = m[0 + r] * x;
+    acc = fmaf(m[4 + r], y, acc);
+    acc = fmaf(m[8 + r], z, acc);
+    acc = fmaf(m[12 + r], w, acc);
+    out[r] = acc;
+  }
+}
+__device__ __forceinline__ void matmul4(const float* a, const float* b, float* out) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) matvec4(a, b[4 * j + 0], b[4 * j + 1], b[4 * j + 2], b[4 * j + 3], out + 4 * j);
+}
+
+// 48-byte interleaved Vertex (src/vk_types.h:97-103) as three 16-byte loads
+struct VertexRaw {
+  float4 a, b, c;  // a = position.xyz, uv_x; b = normal.xyz, uv_y; c = color
+};
+__device__ __forceinline__ VertexRaw load_vertex(const SvrVertex* base, uint32_t index) {
+  const float4* p = reinterpret_cast<const float4*>(base + index);
+  VertexRaw v;
+  v.a = p[0];
+  v.b = p[1];
+  v.c = p[2];
+  return v;
+}
+
+// shaders/mesh.vert:29-38
+__device__ __forceinline__ void mesh_vert(const VertexRaw& v, const float* mvp, const float* world,
+                                          const float* color_factors, VOut& o) {
+  matvec4(mvp, v.a.x, v.a.y, v.a.z, 1.0f, o.clip);
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    float acc = world[0 + r] * v.b.x;
+    acc = fmaf(world[4 + r], v.b.y, acc);
+    acc = fmaf(world[8 + r], v.b.z, acc);
+    o.attr[r] = acc;
+  }
+  o.attr[3] = v.c.x * color_factors[0];
+  o.attr[4] = v.c.y * color_factors[1];
+  o.attr[5] = v.c.z * color_factors[2];
+  o.attr[6] = v.a.w;
+  o.attr[7] = v.b.w;
+}
+
+// shaders/colored_triangle_mesh.vert:28-38
+__device__ __forceinline__ void colored_triangle_mesh_vert(const VertexRaw& v, const float* render_matrix, VOut& o) {
+  matvec4(render_matrix, v.a.x, v.a.y, v.a.z, 1.0f, o.clip);
+  o.attr[0] = o.attr[1] = o.attr[2] = 0.0f;
+  o.attr[3] = v.c.x;
+  o.attr[4] = v.c.y;
+  o.attr[5] = v.c.z;
+  o.attr[6] = v.a.w;
+  o.attr[7] = v.b.w;
+}
+
+// shaders/colored_triangle.vert:6-25
+__device__ __forceinline__ void colored_triangle_vert(int i, VOut& o) {
+  o.clip[0] = (i == 0) ? 1.0f : (i == 1 ? -1.0f : 0.0f);
+  o.clip[1] = (i == 2) ? -1.0f : 1.0f;
+  o.clip[2] = 0.0f;
+  o.clip[3] = 1.0f;
+#pragma unroll
+  for (int k = 0; k < 8; k++) o.attr[k] = 0.0f;
+  o.attr[3] = (i == 0) ? 1.0f : 0.0f;
+  o.attr[4] = (i == 1) ? 1.0f : 0.0f;
+  o.attr[5] = (i == 2) ? 1.0f : 0.0f;
+}
+
+// C2: outcodes against the Vulkan clip volume
+enum { OC_NEAR = 1, OC_FAR = 2, OC_L = 4, OC_R = 8, OC_T = 16, OC_B = 32 };
+__device__ __forceinline__ int outcode(const float* c) {
+  int oc = 0;
+  if (c[2] > c[3]) oc |= OC_NEAR;
+  if (c[2] < 0.0f) oc |= OC_FAR;
+  if (c[0] < -c[3]) oc |= OC_L;
+  if (c[0] > c[3]) oc |= OC_R;
+  if (c[1] < -c[3]) oc |= OC_T;
+  if (c[1] > c[3]) oc |= OC_B;
+  return oc;
+}
+
+struct ScreenV {
+  float xs, ys, zs, rw;
+  bool ok;
+};
+// C3: perspective divide + viewport (0,0,W,H,0,1)
+__device__ __forceinline__ ScreenV to_screen(const float* c, float hw, float hh) {
+  ScreenV s;
+  s.rw = 1.0f / c[3];
+  s.xs = fmaf(c[0] * s.rw, hw, hw);
+  s.ys = fmaf(c[1] * s.rw, hh, hh);
+  s.zs = c[2] * s.rw;
+  s.ok = (fabsf(s.xs) <= GUARD) && (fabsf(s.ys) <= GUARD);
+  return s;
+}
+
+__device__ __forceinline__ void store_invalid(TriRec* rec) {
+  uint4 h;
+  h.x = 1u;           // minx = 1, miny = 0
+  h.y = 0u;           // maxx = 0, maxy = 0
+  h.z = 0u;
+  h.w = 0u;
+  *reinterpret_cast<uint4*>(rec) = h;
+}
+
+// C4..C6: snap, orient, edge functions, attribute deltas.  Returns false when the triangle is
+// dropped (zero area or no pixel centre inside the scissor).
+__device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, const VOut* v1, const VOut* v2,
+                                      ScreenV s0, ScreenV s1, ScreenV s2, uint32_t key, uint32_t draw_flags,
+                                      uint32_t tex, TriRec* out) {
+  int X0 = __float2int_rn(s0.xs * 256.0f), Y0 = __float2int_rn(s0.ys * 256.0f);
+  int X1 = __float2int_rn(s1.xs * 256.0f), Y1 = __float2int_rn(s1.ys * 256.0f);
+  int X2 = __float2int_rn(s2.xs * 256.0f), Y2 = __float2int_rn(s2.ys * 256.0f);
+  long long area2 = (long long)(X1 - X0) * (long long)(Y2 - Y0) - (long long)(X2 - X0) * (long long)(Y1 - Y0);
+  if (area2 == 0) return false;
+  if (area2 < 0) {
+    int t;
+    t = X1; X1 = X2; X2 = t;
+    t = Y1; Y1 = Y2; Y2 = t;
+    const VOut* tv = v1; v1 = v2; v2 = tv;
+    ScreenV ts = s1; s1 = s2; s2 = ts;
+    area2 = -area2;
+  }
+  int xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
+  int ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
+  int pminx = (xmin + 127) >> 8, pmaxx = (xmax - 128) >> 8;
+  int pminy = (ymin + 127) >> 8, pmaxy = (ymax - 128) >> 8;
+  pminx = max(pminx, (int)P.sx);
+  pminy = max(pminy, (int)P.sy);
+  pmaxx = min(pmaxx, (int)(P.sx + P.sw) - 1);
+  pmaxy = min(pmaxy, (int)(P.sy + P.sh) - 1);
+  if (pminx > pmaxx || pminy > pmaxy) return false;
+
+  int Xs[3] = {X0, X1, X2}, Ys[3] = {Y0, Y1, Y2};
+  double A[3], B[3], C[3];
+  uint32_t flags = draw_flags;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    int a = (i + 1) % 3, b = (i + 2) % 3;
+    long long dx = (long long)Xs[b] - Xs[a], dy = (long long)Ys[b] - Ys[a];
+    long long Ae = -dy, Be = dx, Ce = -dx * Ys[a] + dy * Xs[a];
+    bool top_left = (dy < 0) || (dy == 0 && dx > 0);
+    long long Cu = Ce + 128 * (Ae + Be);
+    A[i] = (double)(Ae * 256);
+    B[i] = (double)(Be * 256);
+    C[i] = (double)(Cu + (top_left ? 0 : -1));
+    if (!top_left && i == 1) flags |= F_T1;
+    if (!top_left && i == 2) flags |= F_T2;
+  }
+  float inv_area = 1.0f / (float)(double)area2;
+
+  uint4* q = reinterpret_cast<uint4*>(out);
+  uint4 h;
+  h.x = ((uint32_t)(uint16_t)pminx) | ((uint32_t)(uint16_t)pminy << 16);
+  h.y = ((uint32_t)(uint16_t)pmaxx) | ((uint32_t)(uint16_t)pmaxy << 16);
+  h.z = key;
+  h.w = flags;
+  float zmax = fmaxf(s0.zs, fmaxf(s1.zs, s2.zs));
+  float4 zrow = make_float4(s0.zs, s1.zs - s0.zs, s2.zs - s0.zs, inv_area);
+  q[0] = h;
+  reinterpret_cast<float4*>(out)[1] = zrow;
+  double2* dq = reinterpret_cast<double2*>(out);
+  dq[2] = make_double2(A[0], A[1]);
+  dq[3] = make_double2(A[2], B[0]);
+  dq[4] = make_double2(B[1], B[2]);
+  dq[5] = make_double2(C[0], C[1]);
+  out->C[2] = C[2];
+  out->tex = tex;
+  out->zmax = zmax;
+  // shading half
+  float* f = reinterpret_cast<float*>(out) + 32;
+  float rw0 = s0.rw, rw1 = s1.rw, rw2 = s2.rw;
+  float sh[32];
+  sh[0] = rw0;
+  sh[1] = rw1 - rw0;
+  sh[2] = rw2 - rw0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    float p0 = v0->attr[k] * rw0, p1 = v1->attr[k] * rw1, p2 = v2->attr[k] * rw2;
+    sh[3 + k] = p0;
+    sh[11 + k] = p1 - p0;
+    sh[19 + k] = p2 - p0;
+  }
+#pragma unroll
+  for (int k = 27; k < 32; k++) sh[k] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; k++) reinterpret_cast<float4*>(f)[k] = make_float4(sh[4 * k], sh[4 * k + 1], sh[4 * k + 2], sh[4 * k + 3]);
+  return true;
+}
+
+}  // namespace svr

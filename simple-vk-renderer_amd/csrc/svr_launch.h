@@ -1,0 +1,26 @@
+// svr_launch.h — host-callable launchers of the HIP kernels (one per kernel file).
+#pragma once
+#include "svr_device.h"
+
+namespace svr {
+
+// k_geometry.hip
+void launch_setup(const FrameParams& P, hipStream_t s);
+void launch_clip(const FrameParams& P, hipStream_t s);
+void launch_mesh_vert(const SvrVertex* vtx, uint32_t first, uint32_t n, const float* world16,
+                      const float* viewproj16, const float* color_factors4, float* out_clip,
+                      float* out_varyings, hipStream_t s);
+// k_bin.hip
+void launch_bin_count(const FrameParams& P, hipStream_t s);
+void launch_bin_scan(const FrameParams& P, hipStream_t s);
+void launch_bin_fill(const FrameParams& P, hipStream_t s);
+// k_tile.hip
+void launch_tiles(const FrameParams& P, int color_format, bool count_fragments, hipStream_t s);
+// k_image.hip
+// packed_pixel: the already encoded texel (RGBA16F: 4 halves, RGBA8: low 32 bits)
+void launch_fill_color(void* color, uint32_t n_pixels, int color_format, uint64_t packed_pixel, hipStream_t s);
+void launch_downsample(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh,
+                       hipStream_t s);
+void launch_rgba16f_to_rgba8(const void* src, void* dst, uint32_t n_pixels, hipStream_t s);
+
+}  // namespace svr

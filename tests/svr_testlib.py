@@ -41,9 +41,10 @@ def _finish(r, stats=None):
     return out
 
 
-def render_config1(lib, size=256, color_format=0):
+def render_config1(lib, size=256, color_format=0, instrument=False):
     """colored_triangle.vert/.frag over a white background (BASELINE config 1)."""
     r = lib.create(size, size, color_format)
+    r.set_option(1, 1 if instrument else 0)
     r.clear_color((1, 1, 1, 1))
     r.draw_colored_triangle()
     out = _finish(r)
@@ -51,11 +52,12 @@ def render_config1(lib, size=256, color_format=0):
     return out
 
 
-def render_config2(lib, width=1920, height=1080, color_format=0):
+def render_config2(lib, width=1920, height=1080, color_format=0, instrument=False):
     """textured cube through colored_triangle_mesh.vert + tex_image.frag (BASELINE config 2)."""
     pkg = g.load_package()
     S = pkg.scenes
     r = lib.create(width, height, color_format)
+    r.set_option(1, 1 if instrument else 0)
     cube = S.cube_mesh()
     mesh = r.upload_mesh(cube.indices, cube.vertices)
     img = r.create_image(S.checkerboard_32(), mipmapped=False)
@@ -87,12 +89,13 @@ def setup_sponza(lib, width, height, lod=8, tex_size=64, color_format=0, window=
 
 
 def render_sponza(lib, width, height, lod=8, tex_size=64, color_format=0, scissor=None, camera=None,
-                  instances=None, threads=None):
+                  instances=None, threads=None, instrument=False):
     """mesh.vert/mesh.frag over the synthetic atrium (BASELINE configs 3-5 at reduced size)."""
     r, scene, opaque, transparent = setup_sponza(lib, width, height, lod, tex_size, color_format,
                                                  camera=camera, instances=instances)
     if threads and lib.backend == "cpu-oracle":
         lib.lib.svr_oracle_set_threads(r.h, threads)
+    r.set_option(1, 1 if instrument else 0)
     r.clear_color((1, 1, 1, 1))
     if scissor is not None:
         r.set_scissor(*scissor)
