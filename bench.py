@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py — shaded fragments/s (and frames/s) of the draw_geometry replacement on MI355X.
+
+Workload (BASELINE.json metric, configs[3]): the synthetic Sponza-style scene of SURVEY.md §8d
+(262,144 triangles, 25 mipmapped 1024^2 textures, 2 Transparent materials) at 3840x2160, colour
+target RGBA16F + D32 as in the reference (src/vk_engine.cpp:749,774).  A "step" is one frame:
+draw_background's fill (svr_clear_color) + svr_draw_geometry, inputs resident in HBM; the per-frame
+RenderObject list crosses the ABI from host memory every frame exactly as the reference rebuilds it.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, scene replicated, rank r renders the band of rows [r*H/N,(r+1)*H/N)
+(svr_set_scissor) and the finished bands are exchanged with one RCCL all-gather per frame
+(torch.distributed backend "nccl" == RCCL); total work is fixed -> "scaling": "strong".
+
+Prints ONE JSON line on rank 0.  Extra keys: roofline (tile kernel, HBM bound), cpu_baseline (the
+CPU oracle timed on this host), frames_per_s, rasterized_fragments_per_s, kernel_ms.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--lod", type=int, default=1, help="tessellation divisor of the scene generator (1 = 262,144 triangles)")
+    ap.add_argument("--tex-size", type=int, default=1024)
+    ap.add_argument("--instances", type=int, default=1, help="16 = BASELINE config 5's 4x4 instancing")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, pkg, shaded_per_frame, sc):
+    """The oracle (a scalar C++ port of the path) on this host's cores, same workload, bounded."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import svr_testlib as T
+    ora = T.load_oracle()
+    cores = os.cpu_count() or 1
+    S = pkg.scenes
+    r = ora.create(args.width, args.height, pkg.abi.COLOR_RGBA16F)
+    handles = sc.upload(r)
+    inst = S.config5_instances() if args.instances == 16 else None
+    opaque, transparent = sc.render_objects(handles, instance_transforms=inst)
+    pos, pitch, yaw = S.config5_camera() if args.instances == 16 else S.config3_camera()
+    scene = S.scene_data_struct(pos, pitch, yaw, args.width, args.height)
+    ora.lib.svr_oracle_set_threads(r.h, cores)
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_frames):
+        r.clear_color((1, 1, 1, 1))
+        r.draw_geometry(scene, opaque, transparent)
+    dt = (time.perf_counter() - t0) / args.cpu_frames
+    r.close()
+    return {"value": shaded_per_frame / dt, "unit": "shaded fragments/s", "cores": cores, "kind": "port",
+            "frames_per_s": 1.0 / dt,
+            "sample": f"{args.cpu_frames} full frames of the same workload ({args.width}x{args.height}), "
+                      f"row-band parallel over {cores} threads; fragments counted as the GPU path counts them"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = g.load_package()
+    hip = pkg.load_product_library()
+    S, A = pkg.scenes, pkg.abi
+    W, H = args.width, args.height
+    if H % world:
+        raise SystemExit(f"height {H} is not divisible by {world} ranks")
+
+    sc = S.sponza_like(lod=args.lod, tex_size=args.tex_size)
+    r = hip.create(W, H, A.COLOR_RGBA16F, device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+    r.set_stream(stream.cuda_stream)
+    color = torch.zeros((H, W, 4), dtype=torch.float16, device=dev)   # _draw_image
+    depth = torch.zeros((H, W), dtype=torch.float32, device=dev)      # _depth_image
+    r.bind_targets(color.data_ptr(), depth.data_ptr())
+    handles = sc.upload(r)
+    inst = S.config5_instances() if args.instances == 16 else None
+    opaque, transparent = sc.render_objects(handles, instance_transforms=inst)
+    pos, pitch, yaw = S.config5_camera() if args.instances == 16 else S.config3_camera()
+    scene = S.scene_data_struct(pos, pitch, yaw, W, H)
+    band = H // world
+    r.set_scissor(0, rank * band, W, band)
+    flat = color.view(-1)
+    my_band = flat[rank * band * W * 4:(rank + 1) * band * W * 4]
+
+    def frame():
+        r.clear_color((1.0, 1.0, 1.0, 1.0))
+        r.draw_geometry(scene, opaque, transparent)
+        if world > 1:
+            dist.all_gather_into_tensor(flat, my_band)  # finished rows over xGMI, in place
+
+    def fence():
+        r.sync()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    # one instrumented frame: fragment counts (not timed)
+    r.set_option(A.OPT_COUNT_FRAGMENTS, 1)
+    frame()
+    fence()
+    st = r.get_stats()
+    counts = torch.tensor([st.shaded_fragments, st.rasterized_fragments, st.binned_triangles, st.bin_entries],
+                          dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(counts)
+    shaded, rasterized, binned, entries = [int(v) for v in counts.tolist()]
+    r.set_option(A.OPT_COUNT_FRAGMENTS, 0)
+
+    for _ in range(args.warmup):
+        frame()
+    fence()
+    r.set_option(A.OPT_KERNEL_TIMING, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    st = r.get_stats()
+    r.set_option(A.OPT_KERNEL_TIMING, 0)
+
+    if rank == 0:
+        fps = args.steps / dt
+        counts_scene = sc.counts()
+        # algorithmic bytes of the tile kernel per launch: 5 B per shaded fragment
+        # (one RGBA8 texel at matched LOD x1.25 for the second mip) + one final store of
+        # RGBA16F (8 B) + D32 (4 B) per pixel of this rank's band
+        frag_rank = shaded / world
+        tile_bytes = 5.0 * frag_rank + 12.0 * W * band
+        tile_s = st.tile_ms * 1e-3
+        achieved = tile_bytes / tile_s / 1e9 if tile_s > 0 else 0.0
+        out = {
+            "metric": "shaded fragments/s", "value": shaded * fps, "unit": "fragments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"sponza-style synthetic scene seed 0x53505A41, {counts_scene['triangles']} triangles"
+                                   f" x{args.instances} instances, {W}x{H}, RGBA16F+D32, mesh.vert/mesh.frag"
+                                   f" (BASELINE configs[{4 if args.instances == 16 else 3}])",
+                       "width": W, "height": H, "triangles": counts_scene["triangles"] * args.instances,
+                       "draws": int(len(opaque) + len(transparent)), "textures": f"25 x {args.tex_size}^2 RGBA8 mipmapped",
+                       "parallelism": f"row bands x{world} + all_gather" if world > 1 else "single GPU"},
+            "frames_per_s": fps,
+            "shaded_fragments_per_frame": shaded, "rasterized_fragments_per_frame": rasterized,
+            "rasterized_fragments_per_s": rasterized * fps,
+            "binned_triangles": binned, "bin_entries": entries,
+            "kernel_ms": {"geometry": st.geometry_ms, "binning": st.binning_ms, "tile": st.tile_ms,
+                          "passes": st.timed_passes},
+            "roofline": {"bound": "hbm", "kernel": "tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": tile_bytes, "avg_launch_ms": st.tile_ms},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, pkg, shaded, sc)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,11 +116,17 @@ typedef struct SvrStats {
   /* extensions */
   float gpu_time_ms;             /* device ms of the last completed pass (hipEvent) */
   uint32_t culled_draws;         /* opaque draws rejected by is_visible */
-  uint32_t reserved0;
+  uint32_t timed_passes;         /* passes averaged into the three *_ms fields below */
   uint64_t shaded_fragments;     /* fragment-shader evaluations (no helper lanes) */
   uint64_t rasterized_fragments; /* covered pixel-centre samples that reached the depth test */
   uint64_t binned_triangles;     /* triangles that survived clip/cull/zero-area */
   uint64_t bin_entries;          /* (triangle, tile) pairs */
+  /* mean device ms per pass since SVR_OPT_KERNEL_TIMING was last set, from hipEvents recorded on
+   * the pass's own stream between its kernels */
+  float geometry_ms;             /* vertex + clip + setup kernels */
+  float binning_ms;              /* bin count + scan + fill kernels */
+  float tile_ms;                 /* the tile raster/shade kernel */
+  float reserved1;
 } SvrStats;
 
 typedef struct SvrConfig {
@@ -170,7 +176,8 @@ int svr_write_material(SvrContext* ctx, int pass, const float color_factors[4],
                        SvrSampler color_sampler, SvrMaterial* out);
 
 /* Result of draw_background (src/vk_engine.cpp:1341-1355, gradient_color.comp with
- * data1 == data2): fill the whole colour target with one RGBA value. */
+ * data1 == data2): fill the colour target with one RGBA value.  The fill covers the rows of the
+ * current scissor (all rows unless the multi-GPU path narrowed it: a rank only owns its band). */
 int svr_clear_color(SvrContext* ctx, const float rgba[4]);
 
 /* vkCmdSetScissor (src/vk_engine.cpp:1431-1437).  The reference always passes the full extent and
@@ -206,9 +213,18 @@ int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint
 
 /* Implementation switches (the reference has compile-time flags only).
  * SVR_OPT_COUNT_FRAGMENTS: 1 = count rasterized/shaded fragments and binned triangles with device
- * atomics (instrumented kernels; keep 0 for timed runs). */
-enum SvrOption { SVR_OPT_COUNT_FRAGMENTS = 1 };
+ * atomics (instrumented kernels; keep 0 for timed runs).
+ * SVR_OPT_KERNEL_TIMING: 1 = record hipEvents between the kernels of every pass and average them
+ * into SvrStats.{geometry,binning,tile}_ms; setting it (to 0 or 1) resets the averages. */
+enum SvrOption { SVR_OPT_COUNT_FRAGMENTS = 1, SVR_OPT_KERNEL_TIMING = 2 };
 int svr_set_option(SvrContext* ctx, int option, int64_t value);
+
+/* Parity test hook: ask the next instrumented pass (SVR_OPT_COUNT_FRAGMENTS = 1) to record the
+ * intermediates of the fragment shader invocation that produced pixel (x,y) — barycentrics, 1/w,
+ * uv, derivatives, texel, normal, colour, light, output — and read the 64 floats back.  x < 0
+ * switches tracing off.  Both libraries fill the same slots (see k_tile.hip / svr_oracle.cpp). */
+int svr_debug_trace_pixel(SvrContext* ctx, int x, int y);
+int svr_debug_read_trace(SvrContext* ctx, float out[64]);
 
 /* fence wait (vkWaitForFences, src/vk_engine.cpp:1226) */
 int svr_sync(SvrContext* ctx);

@@ -150,6 +150,7 @@ struct SetupTri {
   int minx, miny, maxx, maxy;  // inclusive pixel bbox, already clamped to the scissor
   int kind;
   bool transparent;
+  uint32_t key;  // submission sequence number + 1
   const Image* image;
   const Sampler* sampler;
 };
@@ -180,6 +181,8 @@ struct SvrContext {
   std::vector<Material> materials;
   SvrStats stats{};
   int threads = 1;
+  int trace_x = -1, trace_y = -1;
+  float trace[64] = {0};
 };
 
 namespace {
@@ -433,6 +436,7 @@ struct PassState {
   SvrContext* ctx;
   std::vector<SetupTri> tris;
   uint64_t binned = 0;
+  uint32_t cur_key = 0;
 };
 
 // triangle setup, C4..C6
@@ -498,6 +502,7 @@ void emit_triangle(PassState& ps, const VOut* v0, const VOut* v1, const VOut* v2
   }
   t.kind = cmd.kind;
   t.transparent = cmd.transparent;
+  t.key = ps.cur_key;
   t.image = cmd.image;
   t.sampler = cmd.sampler;
   ps.tris.push_back(t);
@@ -536,6 +541,7 @@ void run_geometry(PassState& ps, const SvrSceneData* scene, const std::vector<Dr
     if (cmd.kind == PIPE_COLORED_TRIANGLE) {
       VOut v[3];
       for (int i = 0; i < 3; i++) colored_triangle_vert(i, v[i]);
+      ps.cur_key++;
       process_triangle(ps, v, cmd);
       continue;
     }
@@ -552,6 +558,7 @@ void run_geometry(PassState& ps, const SvrSceneData* scene, const std::vector<Dr
         else
           colored_triangle_mesh_vert(vx, cmd.mat, v[k]);
       }
+      ps.cur_key++;
       process_triangle(ps, v, cmd);
     }
   }
@@ -575,7 +582,7 @@ inline float recip_w(const SetupTri& t, float b1, float b2) {
 
 // run the fragment shader of the triangle's pipeline at pixel (px,py); b1,b2 = its barycentrics
 void shade(const SetupTri& t, const SvrSceneData* scene, int px, int py, float b1, float b2,
-           float out[4]) {
+           float out[4], float* trace = nullptr) {
   float r = recip_w(t, b1, b2);
   if (t.kind == PIPE_COLORED_TRIANGLE) {  // shaders/colored_triangle.frag:9-12
     for (int c = 0; c < 3; c++) out[c] = interp(t, 3 + c, b1, b2, r);
@@ -596,6 +603,12 @@ void shade(const SetupTri& t, const SvrSceneData* scene, int px, int py, float b
   float dvdy = (py & 1) ? (v - vv_) : (vv_ - v);
   float tex[4];
   sample_texture(*t.image, *t.sampler, u, v, dudx, dvdx, dudy, dvdy, tex);
+  if (trace) {  // slots shared with k_tile.hip's trace
+    trace[0] = (float)t.key; trace[1] = b1; trace[2] = b2; trace[3] = r; trace[4] = u; trace[5] = v;
+    trace[6] = dudx; trace[7] = dvdx; trace[8] = dudy; trace[9] = dvdy;
+    for (int c = 0; c < 4; c++) trace[11 + c] = tex[c];
+    trace[26] = hb1; trace[27] = hb2; trace[28] = vb1; trace[29] = vb2; trace[30] = hr; trace[31] = vr;
+  }
   if (t.kind == PIPE_TEX_IMAGE) {  // shaders/tex_image.frag:10-12
     for (int c = 0; c < 4; c++) out[c] = tex[c];
     return;
@@ -609,8 +622,13 @@ void shade(const SetupTri& t, const SvrSceneData* scene, int px, int py, float b
     float color = interp(t, 3 + c, b1, b2, r) * tex[c];
     float ambient = color * scene->ambient_color[c];
     out[c] = fmaf(color * light, scene->sunlight_color[3], ambient);
+    if (trace) trace[18 + c] = color;
   }
   out[3] = 1.0f;
+  if (trace) {
+    trace[15] = nx; trace[16] = ny; trace[17] = nz; trace[21] = light;
+    for (int c = 0; c < 4; c++) trace[22 + c] = out[c];
+  }
 }
 
 inline void load_color(SvrContext* ctx, size_t p, float c[4]) {
@@ -647,7 +665,8 @@ void raster_rows(SvrContext* ctx, const SvrSceneData* scene, const std::vector<S
         // depth test GREATER_OR_EQUAL (src/vk_engine.cpp:1659)
         if (!(z >= ctx->depth[p])) continue;
         float src[4];
-        shade(t, scene, px, py, b1, b2, src);
+        bool tr = (px == ctx->trace_x && py == ctx->trace_y);
+        shade(t, scene, px, py, b1, b2, src, tr ? ctx->trace : nullptr);
         n_shaded++;
         if (!t.transparent) {
           ctx->depth[p] = z;  // depth write on, blend off
@@ -658,6 +677,11 @@ void raster_rows(SvrContext* ctx, const SvrSceneData* scene, const std::vector<S
           load_color(ctx, p, dst);
           for (int c = 0; c < 3; c++) out[c] = fmaf(dst[c], dst[3], src[c]);
           out[3] = src[3];
+          if (tr)
+            for (int c = 0; c < 4; c++) {
+              ctx->trace[32 + c] = dst[c];
+              ctx->trace[36 + c] = out[c];
+            }
           store_color(ctx, p, out);
         }
       }
@@ -916,8 +940,9 @@ int svr_write_material(SvrContext* ctx, int pass, const float color_factors[4],
 
 int svr_clear_color(SvrContext* ctx, const float rgba[4]) {
   if (!ctx || !rgba) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_clear_color: null argument");
-  size_t n = (size_t)ctx->W * ctx->H;
-  for (size_t p = 0; p < n; p++) store_color(ctx, p, rgba);
+  // whole rows of the scissor (= the whole target unless the multi-GPU path narrowed it)
+  size_t p0 = (size_t)ctx->sy * ctx->W, p1 = (size_t)(ctx->sy + ctx->sh) * ctx->W;
+  for (size_t p = p0; p < p1; p++) store_color(ctx, p, rgba);
   return SVR_OK;
 }
 
@@ -1080,8 +1105,22 @@ int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint
 
 int svr_set_option(SvrContext* ctx, int option, int64_t) {
   if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
-  if (option != SVR_OPT_COUNT_FRAGMENTS) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_set_option: unknown option");
-  return SVR_OK;  // the oracle always counts
+  if (option != SVR_OPT_COUNT_FRAGMENTS && option != SVR_OPT_KERNEL_TIMING)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_set_option: unknown option");
+  return SVR_OK;  // the oracle always counts and has no kernels to time
+}
+
+int svr_debug_trace_pixel(SvrContext* ctx, int x, int y) {
+  if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  ctx->trace_x = x;
+  ctx->trace_y = y;
+  std::memset(ctx->trace, 0, sizeof(ctx->trace));
+  return SVR_OK;
+}
+int svr_debug_read_trace(SvrContext* ctx, float out[64]) {
+  if (!ctx || !out) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_debug_read_trace: null argument");
+  std::memcpy(out, ctx->trace, sizeof(ctx->trace));
+  return SVR_OK;
 }
 
 int svr_sync(SvrContext* ctx) {

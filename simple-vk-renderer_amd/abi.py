@@ -1,8 +1,8 @@
 """ctypes mirror of include/svr.h and a thin object wrapper over one loaded library.
 
-The same binding drives the product (libsvr_hip.so) and, in tests only, the CPU oracle
-(oracle/libsvr_oracle.so): both export the identical C ABI.  Nothing here picks a library by itself;
-see __init__.load_product_library() for the product and tests/svr_testlib.py for the oracle.
+The same binding drives the product (libsvr_hip.so) and, in tests only, the CPU oracle's library:
+both export the identical C ABI.  Nothing here picks a library by itself; the product is loaded by
+__init__.load_product_library(), the oracle only by the helpers under tests/.
 """
 import ctypes as C
 import os
@@ -38,9 +38,11 @@ class SvrSamplerDesc(C.Structure):
 class SvrStats(C.Structure):  # src/vk_engine.h:16-22 + extensions
     _fields_ = [("frame_time", C.c_float), ("triangle_count", C.c_int32), ("drawcall_count", C.c_int32),
                 ("scene_update_time", C.c_float), ("mesh_draw_time", C.c_float),
-                ("gpu_time_ms", C.c_float), ("culled_draws", C.c_uint32), ("reserved0", C.c_uint32),
+                ("gpu_time_ms", C.c_float), ("culled_draws", C.c_uint32), ("timed_passes", C.c_uint32),
                 ("shaded_fragments", C.c_uint64), ("rasterized_fragments", C.c_uint64),
-                ("binned_triangles", C.c_uint64), ("bin_entries", C.c_uint64)]
+                ("binned_triangles", C.c_uint64), ("bin_entries", C.c_uint64),
+                ("geometry_ms", C.c_float), ("binning_ms", C.c_float), ("tile_ms", C.c_float),
+                ("reserved1", C.c_float)]
 
 
 class SvrConfig(C.Structure):
@@ -64,13 +66,14 @@ FILTER_NEAREST, FILTER_LINEAR = 0, 1
 MIPMAP_NEAREST, MIPMAP_LINEAR = 0, 1
 LOD_CLAMP_NONE = 1000.0
 OPT_COUNT_FRAGMENTS = 1
+OPT_KERNEL_TIMING = 2
 
 # every symbol include/svr.h declares
 SYMBOLS = ["svr_create", "svr_destroy", "svr_set_stream", "svr_bind_targets", "svr_get_targets",
            "svr_upload_mesh", "svr_destroy_mesh", "svr_create_image", "svr_destroy_image",
            "svr_read_image_level", "svr_create_sampler", "svr_write_material", "svr_clear_color",
            "svr_set_scissor", "svr_draw_geometry", "svr_draw_colored_triangle", "svr_draw_tex_image",
-           "svr_run_mesh_vert", "svr_set_option", "svr_sync", "svr_read_color", "svr_read_depth", "svr_get_stats",
+           "svr_run_mesh_vert", "svr_set_option", "svr_debug_trace_pixel", "svr_debug_read_trace", "svr_sync", "svr_read_color", "svr_read_depth", "svr_get_stats",
            "svr_last_error", "svr_backend_name"]
 
 
@@ -117,6 +120,8 @@ class SvrLib:
         L.svr_run_mesh_vert.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
                                         C.POINTER(SvrSceneData), C.c_uint32, P, P]
         L.svr_set_option.argtypes = [P, C.c_int, C.c_int64]
+        L.svr_debug_trace_pixel.argtypes = [P, C.c_int, C.c_int]
+        L.svr_debug_read_trace.argtypes = [P, P]
         L.svr_sync.argtypes = [P]
         L.svr_read_color.argtypes = [P, P, C.c_size_t, C.c_int]
         L.svr_read_depth.argtypes = [P, P, C.c_size_t]
@@ -267,6 +272,14 @@ class Renderer:
 
     def set_option(self, option, value):
         self.lib.check(self.lib.lib.svr_set_option(self.h, option, value))
+
+    def trace_pixel(self, x, y):
+        self.lib.check(self.lib.lib.svr_debug_trace_pixel(self.h, int(x), int(y)))
+
+    def read_trace(self):
+        out = np.zeros(64, dtype=np.float32)
+        self.lib.check(self.lib.lib.svr_debug_read_trace(self.h, out.ctypes.data))
+        return out
 
     def sync(self):
         self.lib.check(self.lib.lib.svr_sync(self.h))

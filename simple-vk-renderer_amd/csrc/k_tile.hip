@@ -139,7 +139,8 @@ __device__ __forceinline__ float interp3(float a0, float da1, float da2, float b
   return fmaf(b2, da2, fmaf(b1, da1, a0)) * r;
 }
 
-__device__ float4 shade_pixel(const FrameParams& P, uint32_t rec, int px, int py) {
+template <bool TRACE>
+__device__ float4 shade_pixel(const FrameParams& P, uint32_t rec, int px, int py, float* trace) {
   const TriRec* tr = P.recs + rec;
   const uint4* q4 = reinterpret_cast<const uint4*>(tr);
   const float4* f4 = reinterpret_cast<const float4*>(tr);
@@ -181,6 +182,12 @@ __device__ float4 shade_pixel(const FrameParams& P, uint32_t rec, int px, int py
   float dvdy = (py & 1) ? (v - vv_) : (vv_ - v);
   const TexBinding& tb = P.tex[tex];
   float4 t = sample_texture(tb, u, v, dudx, dvdx, dudy, dvdy);
+  if (TRACE) {  // slots shared with the oracle's trace (tests/tools only)
+    trace[0] = (float)q4[0].z; trace[1] = b1; trace[2] = b2; trace[3] = r; trace[4] = u; trace[5] = v;
+    trace[6] = dudx; trace[7] = dvdx; trace[8] = dudy; trace[9] = dvdy;
+    trace[11] = t.x; trace[12] = t.y; trace[13] = t.z; trace[14] = t.w;
+    trace[26] = hb1; trace[27] = hb2; trace[28] = vb1; trace[29] = vb2; trace[30] = hr; trace[31] = vr;
+  }
   if (kind == PIPE_TEX_IMAGE) return t;  // shaders/tex_image.frag:10-12
   // shaders/mesh.frag:12-19
   float nx = interp3(s0.w, s2.w, s4.w, b1, b2, r);
@@ -198,6 +205,10 @@ __device__ float4 shade_pixel(const FrameParams& P, uint32_t rec, int px, int py
   o.y = fmaf(cg * light, sunw, cg * P.scene.ambient_color[1]);
   o.z = fmaf(cb * light, sunw, cb * P.scene.ambient_color[2]);
   o.w = 1.0f;
+  if (TRACE) {
+    trace[15] = nx; trace[16] = ny; trace[17] = nz; trace[18] = cr; trace[19] = cg; trace[20] = cb;
+    trace[21] = light; trace[22] = o.x; trace[23] = o.y; trace[24] = o.z; trace[25] = o.w;
+  }
   return o;
 }
 
@@ -208,7 +219,15 @@ struct Codec;
 template <>
 struct Codec<SVR_COLOR_RGBA16F> {
   typedef uint2 enc_t;
+  // The fp32 result must exist before it is rounded to fp16 (two roundings, as an attachment store
+  // after an fp32 shader does): without the barrier hipcc fuses "fma -> cvt" into v_fma_mixlo_f16,
+  // which rounds once and differs from the contract on fp16 ties.
+  static __device__ __forceinline__ float pin(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+  }
   static __device__ __forceinline__ enc_t encode(float4 c) {
+    c.x = pin(c.x); c.y = pin(c.y); c.z = pin(c.z); c.w = pin(c.w);
     uint32_t r = __half_as_ushort(__float2half_rn(c.x)), g = __half_as_ushort(__float2half_rn(c.y));
     uint32_t b = __half_as_ushort(__float2half_rn(c.z)), a = __half_as_ushort(__float2half_rn(c.w));
     return make_uint2(r | (g << 16), b | (a << 16));
@@ -337,8 +356,11 @@ __global__ __launch_bounds__(256) void tile_kernel(FrameParams P) {
     enc[k] = enc_t();
     if (dirty[k]) {
       int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
-      enc[k] = CD::encode(shade_pixel(P, recs[k], px, py));
-      if (INSTR) n_shaded++;
+      enc[k] = CD::encode(shade_pixel<false>(P, recs[k], px, py, nullptr));
+      if (INSTR) {
+        n_shaded++;
+        if (P.trace_buf && px == P.trace_x && py == P.trace_y) (void)shade_pixel<true>(P, recs[k], px, py, P.trace_buf);
+      }
     }
   }
 
@@ -364,10 +386,16 @@ __global__ __launch_bounds__(256) void tile_kernel(FrameParams P) {
         size_t p = (size_t)py * P.W + (size_t)px;
         if (!dirty[k]) enc[k] = reinterpret_cast<const enc_t*>(P.color)[p];  // colour loadOp LOAD
         float4 dst = CD::decode(enc[k]);
-        float4 src = shade_pixel(P, cr[k], px, py);
+        float4 src = shade_pixel<false>(P, cr[k], px, py, nullptr);
         if (INSTR) n_shaded++;
         // enable_blending_additive: rgb = src*ONE + dst*DST_ALPHA, a = src*ONE + dst*ZERO
         float4 o = make_float4(fmaf(dst.x, dst.w, src.x), fmaf(dst.y, dst.w, src.y), fmaf(dst.z, dst.w, src.z), src.w);
+        if (INSTR && P.trace_buf && px == P.trace_x && py == P.trace_y) {
+          (void)shade_pixel<true>(P, cr[k], px, py, P.trace_buf);
+          float* tb = P.trace_buf;
+          tb[32] = dst.x; tb[33] = dst.y; tb[34] = dst.z; tb[35] = dst.w;
+          tb[36] = o.x; tb[37] = o.y; tb[38] = o.z; tb[39] = o.w;
+        }
         enc[k] = CD::encode(o);
         dirty[k] = true;
         last[k] = ck[k];

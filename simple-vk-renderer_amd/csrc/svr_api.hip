@@ -127,9 +127,19 @@ struct SvrContext {
   Counters* h_counters = nullptr;
 
   hipEvent_t ev_start = nullptr, ev_end = nullptr;
+  // SVR_OPT_KERNEL_TIMING: ring of event quadruples (before setup, after clip, after fill, after tiles)
+  static const int TRING = 16;
+  hipEvent_t tev[TRING][4] = {};
+  bool tev_used[TRING] = {};
+  int tev_pos = 0;
+  bool kernel_timing = false;
+  double acc_ms[3] = {0, 0, 0};
+  uint32_t acc_n = 0;
   bool pending = false;      // a pass has been enqueued and not validated yet
   FrameParams last{};        // parameters of that pass, for replay
   bool instrument = false;
+  int trace_x = -1, trace_y = -1;
+  DevBuf d_trace;
   SvrStats stats{};
 };
 
@@ -242,19 +252,47 @@ int stage_slot(SvrContext* ctx, size_t bytes, void** out, int* slot_out) {
   return SVR_OK;
 }
 
+// fold one finished slot of the timing ring into the running means
+int harvest_timing(SvrContext* ctx, int slot) {
+  if (!ctx->tev_used[slot]) return SVR_OK;
+  HIPCHK(hipEventSynchronize(ctx->tev[slot][3]));
+  for (int k = 0; k < 3; k++) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->tev[slot][k], ctx->tev[slot][k + 1]));
+    ctx->acc_ms[k] += ms;
+  }
+  ctx->acc_n++;
+  ctx->tev_used[slot] = false;
+  return SVR_OK;
+}
+
 int enqueue_pass(SvrContext* ctx, const FrameParams& P) {
   hipStream_t s = ctx->stream;
+  int ts = -1;
+  if (ctx->kernel_timing) {
+    ts = ctx->tev_pos;
+    ctx->tev_pos = (ctx->tev_pos + 1) % SvrContext::TRING;
+    if (int e = harvest_timing(ctx, ts)) return e;
+    for (int k = 0; k < 4; k++)
+      if (!ctx->tev[ts][k]) HIPCHK(hipEventCreate(&ctx->tev[ts][k]));
+  }
   HIPCHK(hipMemsetAsync(P.counters, 0, sizeof(Counters), s));
   // tile_count and tile_cursor are adjacent: one memset
-  HIPCHK(hipMemsetAsync(P.tile_count, 0, (size_t)P.n_tiles * 2 * sizeof(uint32_t), s));
-  HIPCHK(hipMemsetAsync(P.tile_cursor, 0, (size_t)P.n_tiles * 2 * sizeof(uint32_t), s));
+  HIPCHK(hipMemsetAsync(P.tile_count, 0, (size_t)P.n_tiles * 4 * sizeof(uint32_t), s));
   HIPCHK(hipEventRecord(ctx->ev_start, s));
+  if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][0], s));
   launch_setup(P, s);
   launch_clip(P, s);
+  if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][1], s));
   launch_bin_count(P, s);
   launch_bin_scan(P, s);
   launch_bin_fill(P, s);
+  if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][2], s));
   launch_tiles(P, ctx->fmt, P.instrument != 0, s);
+  if (ts >= 0) {
+    HIPCHK(hipEventRecord(ctx->tev[ts][3], s));
+    ctx->tev_used[ts] = true;
+  }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev_end, s));
   HIPCHK(hipMemcpyAsync(ctx->h_counters, P.counters, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -348,6 +386,9 @@ int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& 
   P.n_chunks = (uint32_t)n_chunks;
   P.tex = (const TexBinding*)ctx->tex_table.p;
   P.instrument = ctx->instrument ? 1u : 0u;
+  P.trace_x = ctx->trace_x;
+  P.trace_y = ctx->trace_y;
+  P.trace_buf = (ctx->instrument && ctx->trace_x >= 0) ? (float*)ctx->d_trace.p : nullptr;
   if (scene) P.scene = *scene;
   // capacities: generous first guesses; overflow -> replay (finish_pending)
   ctx->clip_cap = std::max<uint32_t>(ctx->clip_cap, std::max<uint32_t>(65536u, P.n_tris / 4u));
@@ -443,7 +484,7 @@ void svr_destroy(SvrContext* ctx) {
   for (auto& im : ctx->images)
     if (im.base) (void)hipFree(im.base);
   DevBuf* bufs[] = {&ctx->tex_table, &ctx->d_draws, &ctx->d_chunks, &ctx->d_recs, &ctx->d_clipq,
-                    &ctx->d_tiles,   &ctx->d_bins,  &ctx->d_counters, &ctx->d_cvt};
+                    &ctx->d_tiles,   &ctx->d_bins,  &ctx->d_counters, &ctx->d_cvt, &ctx->d_trace};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < SvrContext::RING; i++) {
     if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
@@ -452,6 +493,9 @@ void svr_destroy(SvrContext* ctx) {
   if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+  for (int i = 0; i < SvrContext::TRING; i++)
+    for (int k = 0; k < 4; k++)
+      if (ctx->tev[i][k]) (void)hipEventDestroy(ctx->tev[i][k]);
   if (ctx->color_own) (void)hipFree(ctx->color_own);
   if (ctx->depth_own) (void)hipFree(ctx->depth_own);
   delete ctx;
@@ -649,7 +693,10 @@ int svr_clear_color(SvrContext* ctx, const float rgba[4]) {
       packed |= (uint64_t)(uint32_t)std::nearbyintf(c * 255.0f) << (8 * k);
     }
   }
-  launch_fill_color(ctx->color, ctx->W * ctx->H, ctx->fmt, packed, ctx->stream);
+  // whole rows of the scissor (a rank of the multi-GPU path only owns its band)
+  size_t px_bytes = ctx->fmt == SVR_COLOR_RGBA16F ? 8 : 4;
+  char* first_row = (char*)ctx->color + (size_t)ctx->sy * ctx->W * px_bytes;
+  launch_fill_color(first_row, ctx->W * ctx->sh, ctx->fmt, packed, ctx->stream);
   HIPCHK(hipGetLastError());
   return SVR_OK;
 }
@@ -827,8 +874,42 @@ int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint
 
 int svr_set_option(SvrContext* ctx, int option, int64_t value) {
   if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
-  if (option != SVR_OPT_COUNT_FRAGMENTS) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_set_option: unknown option");
-  ctx->instrument = value != 0;
+  if (option == SVR_OPT_COUNT_FRAGMENTS) {
+    ctx->instrument = value != 0;
+    return SVR_OK;
+  }
+  if (option == SVR_OPT_KERNEL_TIMING) {
+    if (int e = use_device(ctx)) return e;
+    for (int i = 0; i < SvrContext::TRING; i++)
+      if (int e = harvest_timing(ctx, i)) return e;
+    ctx->acc_ms[0] = ctx->acc_ms[1] = ctx->acc_ms[2] = 0.0;
+    ctx->acc_n = 0;
+    ctx->kernel_timing = value != 0;
+    return SVR_OK;
+  }
+  return fail(SVR_ERR_INVALID_ARGUMENT, "svr_set_option: unknown option");
+}
+
+int svr_debug_trace_pixel(SvrContext* ctx, int x, int y) {
+  if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  if (int e = use_device(ctx)) return e;
+  if (x >= 0) {
+    if (int e = finish_pending(ctx)) return e;
+    if (int e = ctx->d_trace.ensure(64 * sizeof(float))) return e;
+    HIPCHK(hipMemset(ctx->d_trace.p, 0, 64 * sizeof(float)));
+  }
+  ctx->trace_x = x;
+  ctx->trace_y = y;
+  return SVR_OK;
+}
+
+int svr_debug_read_trace(SvrContext* ctx, float out[64]) {
+  if (!ctx || !out) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_debug_read_trace: null argument");
+  if (!ctx->d_trace.p) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_debug_read_trace: tracing was never enabled");
+  if (int e = use_device(ctx)) return e;
+  if (int e = finish_pending(ctx)) return e;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(out, ctx->d_trace.p, 64 * sizeof(float), hipMemcpyDeviceToHost));
   return SVR_OK;
 }
 
@@ -871,7 +952,15 @@ int svr_read_depth(SvrContext* ctx, float* dst, size_t bytes) {
 int svr_get_stats(SvrContext* ctx, SvrStats* out) {
   if (!ctx || !out) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_get_stats: null argument");
   if (int e = svr_sync(ctx)) return e;
+  for (int i = 0; i < SvrContext::TRING; i++)
+    if (int e = harvest_timing(ctx, i)) return e;
   *out = ctx->stats;
+  out->timed_passes = ctx->acc_n;
+  if (ctx->acc_n) {
+    out->geometry_ms = (float)(ctx->acc_ms[0] / ctx->acc_n);
+    out->binning_ms = (float)(ctx->acc_ms[1] / ctx->acc_n);
+    out->tile_ms = (float)(ctx->acc_ms[2] / ctx->acc_n);
+  }
   return SVR_OK;
 }
 

@@ -117,7 +117,8 @@ struct FrameParams {
   Counters* counters;
   const TexBinding* tex;
   uint32_t instrument;            // count fragments/triangles with device atomics (not in timed runs)
-  uint32_t pad_;
+  int trace_x, trace_y;           // instrumented passes only: dump the shading of this pixel
+  float* trace_buf;               // 64 floats or NULL
   SvrSceneData scene;
 };
 

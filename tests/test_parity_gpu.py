@@ -1,0 +1,225 @@
+"""Parity tests proper: the HIP path (through the C ABI of libsvr_hip.so) against the CPU oracle on
+the same inputs, bit for bit (colour fp16/unorm8 bits, depth f32 bits, mip texels, vertex-stage
+floats), plus size-independent properties at the BASELINE sizes.  Needs a real MI355X."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as g
+import scenarios as SC
+import svr_testlib as T
+
+pkg = g.load_package()
+A, S, GL = pkg.abi, pkg.scenes, pkg.glmath
+pytestmark = pytest.mark.gpu
+
+
+def both(fn, hip, oracle, *a, **k):
+    return fn(hip, *a, **k), fn(oracle, *a, **k)
+
+
+def assert_same(a, b, what, stats=True):
+    T.assert_images_identical(a["color"], b["color"], what + " colour")
+    T.assert_images_identical(a["depth"], b["depth"], what + " depth")
+    T.assert_images_identical(a["rgba8"], b["rgba8"], what + " rgba8 readback")
+    if stats:
+        sa, sb = a["stats"], b["stats"]
+        assert (sa.triangle_count, sa.drawcall_count, sa.culled_draws) == (sb.triangle_count, sb.drawcall_count, sb.culled_draws)
+        assert sa.rasterized_fragments == sb.rasterized_fragments, what + " rasterized fragments"
+        assert sa.binned_triangles == sb.binned_triangles, what + " binned triangles"
+
+
+def test_backend_is_the_hip_library(hip):
+    assert hip.backend == "hip-gfx950"
+    assert hip.path.endswith("libsvr_hip.so")
+
+
+@pytest.mark.parametrize("name", sorted(SC.SCENARIOS))
+def test_scenario(hip, oracle, name):
+    a, b = both(SC.SCENARIOS[name], hip, oracle)
+    assert_same(a, b, name)
+
+
+def test_config1_colored_triangle(hip, oracle):
+    a, b = both(T.render_config1, hip, oracle, 256, instrument=True)
+    assert_same(a, b, "config1")
+    assert a["stats"].rasterized_fragments == 32768
+
+
+def test_config2_textured_cube_full_size(hip, oracle):
+    a, b = both(T.render_config2, hip, oracle, 1920, 1080, instrument=True)
+    assert_same(a, b, "config2")
+    assert a["stats"].triangle_count == 12
+
+
+@pytest.mark.parametrize("size,lod,tex", [((256, 144), 8, 64), ((640, 360), 4, 128), ((333, 187), 2, 64)])
+def test_config3_sponza_reduced(hip, oracle, size, lod, tex):
+    a, b = both(T.render_sponza, hip, oracle, size[0], size[1], lod=lod, tex_size=tex, instrument=True)
+    assert_same(a, b, f"config3 {size} lod {lod}")
+
+
+def test_config3_sponza_full_geometry_1080p(hip, oracle):
+    """All 262,144 triangles at 1920x1080 (the oracle runs row-band parallel to stay in seconds)."""
+    a = T.render_sponza(hip, 1920, 1080, lod=1, tex_size=256, instrument=True)
+    b = T.render_sponza(oracle, 1920, 1080, lod=1, tex_size=256, instrument=True, threads=16)
+    assert_same(a, b, "config3 1080p")
+    assert a["stats"].triangle_count > 200000
+
+
+def test_rgba8_target(hip, oracle):
+    a, b = both(T.render_sponza, hip, oracle, 320, 180, lod=8, tex_size=64, color_format=A.COLOR_RGBA8, instrument=True)
+    assert_same(a, b, "config3 rgba8")
+
+
+def test_scissor_bands_tile_the_frame(hip, oracle):
+    """The multi-GPU decomposition: every band rendered with its own scissor equals that band of the
+    full frame (bands start at rows that are not multiples of the 32-pixel tile)."""
+    full = T.render_sponza(oracle, 480, 270, lod=8, tex_size=64)
+    for k in range(5):
+        y0, y1 = k * 54, (k + 1) * 54
+        band = T.render_sponza(hip, 480, 270, lod=8, tex_size=64, scissor=(0, y0, 480, 54))
+        assert np.array_equal(band["color"][y0:y1], full["color"][y0:y1]), f"band {k} colour"
+        assert np.array_equal(band["depth"][y0:y1], full["depth"][y0:y1]), f"band {k} depth"
+        assert np.all(band["depth"][:y0] == 0) and np.all(band["depth"][y1:] == 0)
+
+
+def test_config5_instanced_reduced(hip, oracle):
+    inst = S.config5_instances()
+    cam = S.config5_camera()
+    a = T.render_sponza(hip, 480, 270, lod=8, tex_size=32, camera=cam, instances=inst, instrument=True)
+    b = T.render_sponza(oracle, 480, 270, lod=8, tex_size=32, camera=cam, instances=inst, instrument=True, threads=8)
+    assert_same(a, b, "config5 reduced")
+    assert a["stats"].drawcall_count > 3000
+
+
+def test_camera_inside_geometry(hip, oracle):
+    """Cameras that sit inside columns / look along walls: near-plane and guard-band clipping."""
+    for cam in (((2.5, 1.0, -5.5), 0.2, 1.0), ((30.0, 8.0, 9.7), -0.3, 3.0), ((54.5, 15.5, 0.0), -1.2, 4.6)):
+        a, b = both(T.render_sponza, hip, oracle, 256, 144, lod=4, tex_size=64, camera=cam, instrument=True)
+        assert_same(a, b, f"camera {cam}")
+
+
+def test_mesh_vert_stage(hip, oracle):
+    sc = T.sponza_scene(8, 64)
+    scene = S.scene_data_struct(*S.config3_camera(), 640, 360)
+    for mesh_idx, world in sc.nodes[:12]:
+        out = []
+        for lib in (hip, oracle):
+            r = lib.create(8, 8)
+            img = r.create_image(S.white_1x1())
+            smp = r.create_sampler()
+            mat = r.write_material(A.PASS_MAIN_COLOR, (0.7, 0.9, 0.3, 1.0), img, smp)
+            m = sc.meshes[mesh_idx]
+            mh = r.upload_mesh(m.indices, m.vertices)
+            out.append(r.run_mesh_vert(mh, 0, m.vertices.size, world, scene, mat))
+            r.close()
+        assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)), "gl_Position bits"
+        assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32)), "varyings bits"
+
+
+def test_mip_generation(hip, oracle):
+    rng = np.random.default_rng(17)
+    for (h, w) in ((64, 64), (32, 128), (1, 1), (37, 21), (256, 256)):
+        tex = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        levels = []
+        for lib in (hip, oracle):
+            r = lib.create(8, 8)
+            img = r.create_image(tex, mipmapped=True)
+            n = int(np.floor(np.log2(max(h, w)))) + 1
+            levels.append([r.read_image_level(img, l) for l in range(n)])
+            r.close()
+        for l, (x, y) in enumerate(zip(*levels)):
+            assert np.array_equal(x, y), f"{w}x{h} level {l}"
+
+
+def test_deferred_shading_never_shades_more_than_forward(hip, oracle):
+    a, b = both(T.render_sponza, hip, oracle, 320, 180, lod=8, tex_size=64, instrument=True)
+    assert a["stats"].shaded_fragments <= b["stats"].shaded_fragments
+    assert a["stats"].shaded_fragments >= int((a["depth"] > 0).sum())
+
+
+def test_idempotent_and_stateless_across_frames(hip):
+    """Rendering the same frame repeatedly into the same context gives the same bits (the pass
+    clears its own counters / bins; depth CLEAR is part of the pass)."""
+    r, scene, opaque, transparent = T.setup_sponza(hip, 640, 360, lod=4, tex_size=64)
+    frames = []
+    for _ in range(3):
+        r.clear_color((1, 1, 1, 1))
+        r.draw_geometry(scene, opaque, transparent)
+        r.sync()
+        frames.append((r.read_color().copy(), r.read_depth().copy()))
+    r.close()
+    for c, d in frames[1:]:
+        assert np.array_equal(c, frames[0][0]) and np.array_equal(d, frames[0][1])
+
+
+def test_full_size_properties_4k(hip):
+    """BASELINE configs[3] at full size: properties that need no oracle.  Band decomposition (8 bands
+    of 270 rows, the 8-GPU split) reproduces the single full-frame render bit for bit; every covered
+    pixel was shaded exactly once plus the transparent layers; depth lies in [0,1]."""
+    W, H = 3840, 2160
+    r, scene, opaque, transparent = T.setup_sponza(hip, W, H, lod=1, tex_size=256)
+    r.set_option(A.OPT_COUNT_FRAGMENTS, 1)
+    r.clear_color((1, 1, 1, 1))
+    st0 = r.draw_geometry(scene, opaque, transparent)
+    r.sync()
+    full_c, full_d = r.read_color().copy(), r.read_depth().copy()
+    st = r.get_stats()
+    assert st0.triangle_count > 200000
+    assert 0.0 <= full_d.min() and full_d.max() <= 1.0
+    assert st.shaded_fragments >= int((full_d > 0).sum())
+    assert st.rasterized_fragments >= st.shaded_fragments
+    tot = 0
+    for k in range(8):
+        r.set_scissor(0, k * 270, W, 270)
+        r.clear_color((1, 1, 1, 1))
+        r.draw_geometry(scene, opaque, transparent)
+        r.sync()
+        tot += r.get_stats().rasterized_fragments
+    # the last call leaves bands 0..7 all rendered by their own pass
+    assert np.array_equal(r.read_color(), full_c)
+    assert np.array_equal(r.read_depth(), full_d)
+    assert tot == st.rasterized_fragments  # every fragment belongs to exactly one band
+    r.close()
+
+
+def test_errors_on_the_hip_library(hip):
+    r = hip.create(16, 16)
+    with pytest.raises(pkg.SvrError) as ei:
+        r.upload_mesh(np.array([0, 1, 5], np.uint32), SC.clip_quad(-1, -1, 1, 1, 0.5))
+    assert ei.value.code == -1
+    mesh = r.upload_mesh(SC.QUAD_IDX, SC.clip_quad(-1, -1, 1, 1, 0.5))
+    img = r.create_image(S.white_1x1())
+    smp = r.create_sampler()
+    mo = r.write_material(A.PASS_MAIN_COLOR, (1, 1, 1, 1), img, smp)
+    mt = r.write_material(A.PASS_TRANSPARENT, (1, 1, 1, 1), img, smp)
+    sc = SC.identity_scene()
+    for bad, code in ((SC.render_object(7, mo, 0, 6), -4), (SC.render_object(mesh, 9, 0, 6), -4),
+                      (SC.render_object(mesh, mo, 3, 6), -1), (SC.render_object(mesh, mt, 0, 6), -1)):
+        with pytest.raises(pkg.SvrError) as ei:
+            r.draw_geometry(sc, SC.objs([bad]))
+        assert ei.value.code == code
+    with pytest.raises(pkg.SvrError):
+        r.set_scissor(8, 8, 16, 4)
+    with pytest.raises(pkg.SvrError):
+        hip.create(0, 16)
+    r.close()
+
+
+def test_bound_targets_and_stream(hip, oracle):
+    """Render into caller-owned device memory (torch tensors) on a caller-owned stream."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    W, H = 320, 180
+    r, scene, opaque, transparent = T.setup_sponza(hip, W, H, lod=8, tex_size=64)
+    color = torch.zeros((H, W, 4), dtype=torch.float16, device=dev)
+    depth = torch.full((H, W), 7.0, dtype=torch.float32, device=dev)
+    s = torch.cuda.Stream(device=dev)
+    r.set_stream(s.cuda_stream)
+    r.bind_targets(color.data_ptr(), depth.data_ptr())
+    r.clear_color((1, 1, 1, 1))
+    r.draw_geometry(scene, opaque, transparent)
+    r.sync()
+    ref = T.render_sponza(oracle, W, H, lod=8, tex_size=64)
+    assert np.array_equal(color.cpu().numpy().view(np.uint16), ref["color"])
+    assert np.array_equal(depth.cpu().numpy(), ref["depth"])
+    r.close()

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--lod", type=int, default=8)
     ap.add_argument("--tex", type=int, default=64)
     ap.add_argument("--configs", default="1,2,3")
+    ap.add_argument("--trace", default="", help="x,y: dump the fragment-shader intermediates of that pixel")
     args = ap.parse_args()
     w, h = [int(v) for v in args.size.split("x")]
     pkg = g.load_package()
@@ -63,8 +64,19 @@ def main():
         report("config2", a, b)
     if "3" in args.configs:
         print("config 3")
-        a, b = both(T.render_sponza, w, h, lod=args.lod, tex_size=args.tex, instrument=True)
+        trace = tuple(int(v) for v in args.trace.split(",")) if args.trace else None
+        a, b = both(T.render_sponza, w, h, lod=args.lod, tex_size=args.tex, instrument=True, trace=trace)
         report("config3", a, b)
+        if trace:
+            names = {0: "key", 1: "b1", 2: "b2", 3: "r", 4: "u", 5: "v", 6: "dudx", 7: "dvdx", 8: "dudy", 9: "dvdy",
+                     11: "tex.r", 12: "tex.g", 13: "tex.b", 14: "tex.a", 15: "nx", 16: "ny", 17: "nz", 18: "col.r",
+                     19: "col.g", 20: "col.b", 21: "light", 22: "out.r", 23: "out.g", 24: "out.b", 25: "out.a",
+                     26: "hb1", 27: "hb2", 28: "vb1", 29: "vb2", 30: "hr", 31: "vr", 32: "dst.r", 33: "dst.g",
+                     34: "dst.b", 35: "dst.a", 36: "bl.r", 37: "bl.g", 38: "bl.b", 39: "bl.a"}
+            ta, tb = a["trace"], b["trace"]
+            for i, nm in names.items():
+                flag = "" if ta[i].tobytes() == tb[i].tobytes() else "   <-- differs"
+                print(f"   {nm:6s} hip={float(ta[i])!r:24} oracle={float(tb[i])!r:24}{flag}")
 
 
 if __name__ == "__main__":
