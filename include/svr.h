@@ -225,6 +225,14 @@ int svr_set_option(SvrContext* ctx, int option, int64_t value);
  * switches tracing off.  Both libraries fill the same slots (see k_tile.hip / svr_oracle.cpp). */
 int svr_debug_trace_pixel(SvrContext* ctx, int x, int y);
 int svr_debug_read_trace(SvrContext* ctx, float out[64]);
+/* Profiling hook: per-tile triangle counts of the last pass (32x32-pixel tiles of the scissor,
+ * row-major; first the opaque bins, then the transparent bins).  *n_tiles receives the tile count;
+ * counts may be NULL to query it, else must hold 2 * n_tiles entries.  HIP library only. */
+int svr_debug_read_bins(SvrContext* ctx, uint32_t* counts, size_t capacity, uint32_t* n_tiles);
+/* Profiling hook: shader-clock cycles each tile's workgroup spent in its four phases (visibility,
+ * shading, transparent layers, write-back) during the last instrumented pass: 4 * n_tiles entries.
+ * HIP library only. */
+int svr_debug_read_tile_cycles(SvrContext* ctx, uint32_t* cycles, size_t capacity);
 
 /* fence wait (vkWaitForFences, src/vk_engine.cpp:1226) */
 int svr_sync(SvrContext* ctx);

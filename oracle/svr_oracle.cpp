@@ -1123,6 +1123,14 @@ int svr_debug_read_trace(SvrContext* ctx, float out[64]) {
   return SVR_OK;
 }
 
+int svr_debug_read_bins(SvrContext*, uint32_t*, size_t, uint32_t*) {
+  return fail(SVR_ERR_UNSUPPORTED, "svr_debug_read_bins: the CPU oracle does not bin");
+}
+
+int svr_debug_read_tile_cycles(SvrContext*, uint32_t*, size_t) {
+  return fail(SVR_ERR_UNSUPPORTED, "svr_debug_read_tile_cycles: the CPU oracle has no tiles");
+}
+
 int svr_sync(SvrContext* ctx) {
   if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
   return SVR_OK;

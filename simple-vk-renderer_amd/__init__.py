@@ -28,6 +28,13 @@ def load_product_library():
             raise RuntimeError(
                 f"{PRODUCT_LIBRARY} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  The product has no CPU fallback.")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64 and must be the one that
+        # gets loaded (same SONAME as /opt/rocm's), or torch.cuda later finds "No HIP GPUs" and stream
+        # handles could not be shared.  Import torch first whenever it is installed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _product = SvrLib(PRODUCT_LIBRARY)
         if _product.backend != "hip-gfx950":
             raise RuntimeError(f"{PRODUCT_LIBRARY} reports backend {_product.backend!r}, expected 'hip-gfx950'")

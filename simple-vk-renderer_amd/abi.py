@@ -73,7 +73,7 @@ SYMBOLS = ["svr_create", "svr_destroy", "svr_set_stream", "svr_bind_targets", "s
            "svr_upload_mesh", "svr_destroy_mesh", "svr_create_image", "svr_destroy_image",
            "svr_read_image_level", "svr_create_sampler", "svr_write_material", "svr_clear_color",
            "svr_set_scissor", "svr_draw_geometry", "svr_draw_colored_triangle", "svr_draw_tex_image",
-           "svr_run_mesh_vert", "svr_set_option", "svr_debug_trace_pixel", "svr_debug_read_trace", "svr_sync", "svr_read_color", "svr_read_depth", "svr_get_stats",
+           "svr_run_mesh_vert", "svr_set_option", "svr_debug_trace_pixel", "svr_debug_read_trace", "svr_debug_read_bins", "svr_debug_read_tile_cycles", "svr_sync", "svr_read_color", "svr_read_depth", "svr_get_stats",
            "svr_last_error", "svr_backend_name"]
 
 
@@ -122,6 +122,8 @@ class SvrLib:
         L.svr_set_option.argtypes = [P, C.c_int, C.c_int64]
         L.svr_debug_trace_pixel.argtypes = [P, C.c_int, C.c_int]
         L.svr_debug_read_trace.argtypes = [P, P]
+        L.svr_debug_read_bins.argtypes = [P, P, C.c_size_t, C.POINTER(C.c_uint32)]
+        L.svr_debug_read_tile_cycles.argtypes = [P, P, C.c_size_t]
         L.svr_sync.argtypes = [P]
         L.svr_read_color.argtypes = [P, P, C.c_size_t, C.c_int]
         L.svr_read_depth.argtypes = [P, P, C.c_size_t]
@@ -275,6 +277,21 @@ class Renderer:
 
     def trace_pixel(self, x, y):
         self.lib.check(self.lib.lib.svr_debug_trace_pixel(self.h, int(x), int(y)))
+
+    def read_bins(self):
+        """(opaque counts, transparent counts) per 32x32 tile of the last pass, row-major."""
+        n = C.c_uint32()
+        self.lib.check(self.lib.lib.svr_debug_read_bins(self.h, None, 0, C.byref(n)))
+        out = np.zeros(2 * n.value, dtype=np.uint32)
+        self.lib.check(self.lib.lib.svr_debug_read_bins(self.h, out.ctypes.data, out.size, C.byref(n)))
+        return out[:n.value], out[n.value:]
+
+    def read_tile_cycles(self):
+        n = C.c_uint32()
+        self.lib.check(self.lib.lib.svr_debug_read_bins(self.h, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 4), dtype=np.uint32)
+        self.lib.check(self.lib.lib.svr_debug_read_tile_cycles(self.h, out.ctypes.data, out.size))
+        return out
 
     def read_trace(self):
         out = np.zeros(64, dtype=np.float32)

@@ -134,6 +134,31 @@ __global__ __launch_bounds__(1024) void scan_kernel(FrameParams P) {
     P.counters->total_entries = total;
     if (total > P.bin_cap) atomicOr(&P.counters->overflow, 4u);
   }
+  // Tile launch order for the tile kernel: heaviest class first (longest-processing-time-first), so
+  // the few tiles with hundreds of triangles start at once and the light ones fill in behind them.
+  // Class = bit length of (opaque + 2*transparent) entries; order inside a class is arbitrary.
+  __shared__ uint32_t cls_count[33], cls_base[33];
+  __syncthreads();
+  if (threadIdx.x < 33) cls_count[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < P.n_tiles; t += 1024u) {
+    uint32_t wgt = P.tile_count[t] + 2u * P.tile_count[P.n_tiles + t];
+    atomicAdd(&cls_count[32 - __clz(wgt)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run2 = 0;
+    for (int c = 32; c >= 0; c--) {
+      cls_base[c] = run2;
+      run2 += cls_count[c];
+    }
+  }
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < P.n_tiles; t += 1024u) {
+    uint32_t wgt = P.tile_count[t] + 2u * P.tile_count[P.n_tiles + t];
+    uint32_t pos = atomicAdd(&cls_base[32 - __clz(wgt)], 1u);
+    P.tile_order[pos] = t;
+  }
 }
 
 static inline uint32_t bin_blocks(const FrameParams& P) { return (P.n_tris + P.extra_cap + 255u) / 256u; }

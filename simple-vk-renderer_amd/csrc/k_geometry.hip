@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void setup_kernel(FrameParams P) {
   if (((c0 | c1 | c2) & (OC_NEAR | OC_FAR)) == 0) {
     ScreenV s0 = to_screen(v0.clip, hw, hh), s1 = to_screen(v1.clip, hw, hh), s2 = to_screen(v2.clip, hw, hh);
     if (s0.ok && s1.ok && s2.ok) {
-      if (setup_triangle(P, &v0, &v1, &v2, s0, s1, s2, seq + 1, d.flags, d.tex, rec)) {
+      if (setup_triangle(P, &v0, &v1, &v2, s0, s1, s2, seq + 1, d.flags, P.tex[d.tex], rec)) {
         if (P.instrument) atomicAdd(&P.counters->binned, 1ull);
       } else {
         store_invalid(rec);
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64) void clip_kernel(FrameParams P) {
       if (!(s0.ok && s1.ok && s2.ok)) continue;
       if (!(poly[0].clip[3] > 0.0f && poly[i].clip[3] > 0.0f && poly[i + 1].clip[3] > 0.0f)) continue;
       TriRec tmp;
-      if (!setup_triangle(P, &poly[0], &poly[i], &poly[i + 1], s0, s1, s2, seq + 1, d.flags, d.tex, &tmp)) continue;
+      if (!setup_triangle(P, &poly[0], &poly[i], &poly[i + 1], s0, s1, s2, seq + 1, d.flags, P.tex[d.tex], &tmp)) continue;
       uint32_t slot = atomicAdd(&P.counters->n_extra, 1u);
       if (slot >= P.extra_cap) {
         atomicOr(&P.counters->overflow, 2u);

@@ -10,19 +10,24 @@
 // One 256-thread workgroup per 32x32 tile; wave w owns the 16x16 quadrant w and lane l owns four
 // pixels of it (one per 8x8 block), so depth, sequence key and winning triangle live in VGPRs and
 // never touch LDS or HBM until the single final store.  The tile's triangle bin is staged through
-// LDS in batches (coalesced 128-byte coverage halves), every wave walks the batch with wave-uniform
-// bbox rejects.  Coverage is exact: edge functions are integers < 2^53 evaluated in fp64.
+// LDS in batches of 64 (coalesced 128-byte coverage halves).  Each wave first classifies the whole
+// batch in one step (lane i tests triangle i's bbox against the wave's quadrant, __ballot), then
+// walks only the accepted triangles with the next one's LDS reads already in flight.  Coverage is
+// exact: edge functions are integers < 2^53 evaluated in fp64.
 //   phase A  opaque visibility: per pixel max over (depth, submission key) == in-order GE test
 //   phase B  shade each visible pixel once (deferred: identical result, no overdraw shading)
 //   phase C  transparent fragments peeled per pixel in submission order, blended at target precision
 //   phase D  store colour where touched, depth everywhere (the CLEAR is fused here)
+// The kernel is latency-bound, not ALU- or HBM-bound (DESIGN.md "Tile kernel"): the register budget
+// is capped for 4 workgroups per CU and every dependent-load chain is at most two deep (record ->
+// texels; the texture descriptor travels inside the record).
 #include <hip/hip_fp16.h>
 
 #include "svr_launch.h"
 
 namespace svr {
 
-constexpr int BATCH = 64;  // triangles staged per LDS batch: 64 x 128 B = 8 KiB
+constexpr int BATCH = 64;  // triangles staged per LDS batch == wave size: 64 x 128 B = 8 KiB
 
 struct CovTri {  // the coverage half as read back from LDS (wave-uniform values)
   int minx, miny, maxx, maxy;
@@ -54,8 +59,6 @@ constexpr float kInv255 = 0x1.010102p-8f;
 constexpr float kG0 = 0x1.c51282p-2f, kG1 = -0x1.14a3a2p-2f, kG2 = 0x1.37536ap-3f, kG3 = -0x1.778474p-5f;
 
 __device__ __forceinline__ float lod_from_rho2(float rho2) {
-  if (!(rho2 >= 0x1p-100f)) return -50.0f;
-  if (!(rho2 <= 0x1p+100f)) return 50.0f;
   uint32_t bits = f2u(rho2);
   int e = (int)(bits >> 23) - 127;
   float m = u2f((bits & 0x7fffffu) | 0x3f800000u);
@@ -63,74 +66,53 @@ __device__ __forceinline__ float lod_from_rho2(float rho2) {
   float g = fmaf(fmaf(fmaf(kG3, t, kG2), t, kG1), t, kG0);
   float s = t * (1.0f - t);
   float l = fmaf(s, g, t);
-  return 0.5f * ((float)e + l);
+  float lam = 0.5f * ((float)e + l);
+  lam = (rho2 <= 0x1p+100f) ? lam : 50.0f;
+  lam = (rho2 >= 0x1p-100f) ? lam : -50.0f;  // also NaN
+  return lam;
 }
 
-__device__ __forceinline__ float4 unpack_texel(uint32_t t) {
-  return make_float4((float)(t & 0xffu) * kInv255, (float)((t >> 8) & 0xffu) * kInv255,
-                     (float)((t >> 16) & 0xffu) * kInv255, (float)(t >> 24) * kInv255);
-}
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }
 
-__device__ __forceinline__ float4 sample_level(const TexBinding& tb, uint32_t level, uint32_t filter, float u, float v) {
-  u = (fabsf(u) < 8388608.0f) ? u : 0.0f;
-  v = (fabsf(v) < 8388608.0f) ? v : 0.0f;
-  int wl = (int)max(tb.w >> level, 1u), hl = (int)max(tb.h >> level, 1u);
-  const uint32_t* texels = reinterpret_cast<const uint32_t*>(tb.base + tb.level_offset[level]);
+struct TexD {
+  const uint8_t* base;
+  uint32_t w, h, lw, lh, levels, filters;
+  float min_lod, max_lod;
+};
+
+// the four texel byte offsets and the two weights of one mip level; NEAREST is the same footprint
+// with both taps on floor(U) and weight 0 (lerp(t,t,0) == t exactly), so the path is branch-free
+struct Taps {
+  uint32_t o00, o10, o01, o11;
+  float alpha, beta;
+};
+__device__ __forceinline__ Taps level_taps(const TexD& t, uint32_t level, bool linear, float u, float v) {
+  int wl = (int)max(t.w >> level, 1u), hl = (int)max(t.h >> level, 1u);
+  uint32_t base = mip_offset(t.lw, t.lh, level);
   float U = (u - floorf(u)) * (float)wl;
   float V = (v - floorf(v)) * (float)hl;
-  if (filter == SVR_FILTER_NEAREST) {
-    int i = (int)floorf(U), j = (int)floorf(V);
-    if (i >= wl) i -= wl;
-    if (j >= hl) j -= hl;
-    return unpack_texel(texels[j * wl + i]);
-  }
   float Uh = U - 0.5f, Vh = V - 0.5f;
-  float fu = floorf(Uh), fv = floorf(Vh);
-  float alpha = Uh - fu, beta = Vh - fv;
+  float fu = floorf(linear ? Uh : U), fv = floorf(linear ? Vh : V);
+  Taps tp;
+  tp.alpha = linear ? Uh - fu : 0.0f;
+  tp.beta = linear ? Vh - fv : 0.0f;
   int i0 = (int)fu, j0 = (int)fv;
-  int i1 = i0 + 1, j1 = j0 + 1;
+  int i1 = linear ? i0 + 1 : i0, j1 = linear ? j0 + 1 : j0;
   if (i0 < 0) i0 += wl;
+  if (i0 >= wl) i0 -= wl;
   if (i1 >= wl) i1 -= wl;
   if (j0 < 0) j0 += hl;
+  if (j0 >= hl) j0 -= hl;
   if (j1 >= hl) j1 -= hl;
-  float4 t00 = unpack_texel(texels[j0 * wl + i0]), t10 = unpack_texel(texels[j0 * wl + i1]);
-  float4 t01 = unpack_texel(texels[j1 * wl + i0]), t11 = unpack_texel(texels[j1 * wl + i1]);
-  float4 o;
-  o.x = lerpf(lerpf(t00.x, t10.x, alpha), lerpf(t01.x, t11.x, alpha), beta);
-  o.y = lerpf(lerpf(t00.y, t10.y, alpha), lerpf(t01.y, t11.y, alpha), beta);
-  o.z = lerpf(lerpf(t00.z, t10.z, alpha), lerpf(t01.z, t11.z, alpha), beta);
-  o.w = lerpf(lerpf(t00.w, t10.w, alpha), lerpf(t01.w, t11.w, alpha), beta);
-  return o;
+  tp.o00 = base + (uint32_t)(j0 * wl + i0) * 4u;
+  tp.o10 = base + (uint32_t)(j0 * wl + i1) * 4u;
+  tp.o01 = base + (uint32_t)(j1 * wl + i0) * 4u;
+  tp.o11 = base + (uint32_t)(j1 * wl + i1) * 4u;
+  return tp;
 }
-
-__device__ __forceinline__ float4 sample_texture(const TexBinding& tb, float u, float v, float dudx, float dvdx,
-                                                 float dudy, float dvdy) {
-  float W0 = (float)tb.w, H0 = (float)tb.h;
-  float mx = dudx * W0, my = dvdx * H0;
-  float nx = dudy * W0, ny = dvdy * H0;
-  float rx2 = fmaf(mx, mx, my * my);
-  float ry2 = fmaf(nx, nx, ny * ny);
-  float rho2 = fmaxf(rx2, ry2);
-  float lambda = lod_from_rho2(rho2);
-  lambda = fminf(fmaxf(lambda, tb.min_lod), tb.max_lod);
-  uint32_t filter = (lambda <= 0.0f) ? (tb.filters & 1u) : ((tb.filters >> 1) & 1u);
-  int q = (int)tb.levels - 1;
-  if (((tb.filters >> 2) & 1u) == SVR_MIPMAP_NEAREST) {
-    int d = (int)ceilf(lambda + 0.5f) - 1;
-    d = min(max(d, 0), q);
-    return sample_level(tb, (uint32_t)d, filter, u, v);
-  }
-  float lc = fminf(fmaxf(lambda, 0.0f), (float)q);
-  float fl = floorf(lc);
-  int dhi = (int)fl;
-  float delta = lc - fl;
-  float4 hi = sample_level(tb, (uint32_t)dhi, filter, u, v);
-  if (delta == 0.0f) return hi;
-  int dlo = min(dhi + 1, q);
-  float4 lo = sample_level(tb, (uint32_t)dlo, filter, u, v);
-  return make_float4(lerpf(hi.x, lo.x, delta), lerpf(hi.y, lo.y, delta), lerpf(hi.z, lo.z, delta),
-                     lerpf(hi.w, lo.w, delta));
+__device__ __forceinline__ float chan(uint32_t t, int c) { return (float)((t >> (8 * c)) & 0xffu) * kInv255; }
+__device__ __forceinline__ float bilerp(uint32_t t00, uint32_t t10, uint32_t t01, uint32_t t11, int c, float a, float b) {
+  return lerpf(lerpf(chan(t00, c), chan(t10, c), a), lerpf(chan(t01, c), chan(t11, c), a), b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -140,34 +122,45 @@ __device__ __forceinline__ float interp3(float a0, float da1, float da2, float b
 }
 
 template <bool TRACE>
-__device__ float4 shade_pixel(const FrameParams& P, uint32_t rec, int px, int py, float* trace) {
+__device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec, int px, int py, float* trace) {
   const TriRec* tr = P.recs + rec;
   const uint4* q4 = reinterpret_cast<const uint4*>(tr);
   const float4* f4 = reinterpret_cast<const float4*>(tr);
   const double2* d2 = reinterpret_cast<const double2*>(tr);
-  uint32_t flags = q4[0].w;
-  float inv_area = f4[1].w;
-  double A1 = d2[2].y, B1 = d2[4].x, C1 = d2[5].y;
-  double A2 = d2[3].x, B2 = d2[4].y, C2 = d2[6].x;
-  uint32_t tex = tr->tex;
+  // every load of the record is issued up front: nothing below depends on another load except the texels
+  uint4 hdr = q4[0];
+  float4 zrow = f4[1];
+  double2 c2 = d2[2], c3 = d2[3], c4 = d2[4], c5 = d2[5], c6 = d2[6];
+  uint4 td = q4[7];
+  float4 s0 = f4[8], s1 = f4[9], s2 = f4[10], s3 = f4[11], s4 = f4[12], s5 = f4[13], s6 = f4[14];
+  // s0 = q0,dq1,dq2,a0[0] | s1 = a0[1..4] | s2 = a0[5..7],da1[0] | s3 = da1[1..4] | s4 = da1[5..7],da2[0]
+  // s5 = da2[1..4] | s6 = da2[5..7],pad
+  uint32_t flags = hdr.w;
+  float inv_area = zrow.w;
+  double A1 = c2.y, B1 = c4.x, C1 = c5.y;
+  double A2 = c3.x, B2 = c4.y, C2 = c6.x;
+  TexD t;
+  t.base = reinterpret_cast<const uint8_t*>(__double_as_longlong(c6.y));
+  t.w = td.x & 0xffffu;
+  t.h = td.x >> 16;
+  t.lw = td.y & 0xffu;
+  t.lh = (td.y >> 8) & 0xffu;
+  t.levels = (td.y >> 16) & 0xffu;
+  t.filters = td.y >> 24;
+  t.min_lod = u2f(td.z);
+  t.max_lod = u2f(td.w);
   // unbiased edge values at the pixel and at its horizontal / vertical quad partners
   double dx = (double)px, dy = (double)py;
   double e1 = fma(A1, dx, fma(B1, dy, C1)) + ((flags & F_T1) ? 1.0 : 0.0);
   double e2 = fma(A2, dx, fma(B2, dy, C2)) + ((flags & F_T2) ? 1.0 : 0.0);
   float b1 = (float)e1 * inv_area, b2 = (float)e2 * inv_area;
-  // shading half
-  float4 s0 = f4[8], s1 = f4[9], s2 = f4[10], s3 = f4[11], s4 = f4[12], s5 = f4[13], s6 = f4[14];
-  // s0 = q0,dq1,dq2,a0[0] | s1 = a0[1..4] | s2 = a0[5..7],da1[0] | s3 = da1[1..4] | s4 = da1[5..7],da2[0]
-  // s5 = da2[1..4] | s6 = da2[5..7],pad
   float q0 = s0.x, dq1 = s0.y, dq2 = s0.z;
   float r = 1.0f / fmaf(b2, dq2, fmaf(b1, dq1, q0));
   uint32_t kind = (flags >> F_KIND_SHIFT) & 3u;
-  if (kind == PIPE_COLORED_TRIANGLE) {  // shaders/colored_triangle.frag:9-12
-    float cr = interp3(s1.z, s3.z, s5.z, b1, b2, r);
-    float cg = interp3(s1.w, s3.w, s5.w, b1, b2, r);
-    float cb = interp3(s2.x, s4.x, s6.x, b1, b2, r);
-    return make_float4(cr, cg, cb, 1.0f);
-  }
+  float cr = interp3(s1.z, s3.z, s5.z, b1, b2, r);
+  float cg = interp3(s1.w, s3.w, s5.w, b1, b2, r);
+  float cb = interp3(s2.x, s4.x, s6.x, b1, b2, r);
+  if (kind == PIPE_COLORED_TRIANGLE) return make_float4(cr, cg, cb, 1.0f);  // shaders/colored_triangle.frag:9-12
   float u = interp3(s2.y, s4.y, s6.y, b1, b2, r), v = interp3(s2.z, s4.z, s6.z, b1, b2, r);
   double sxp = (px & 1) ? -1.0 : 1.0, syp = (py & 1) ? -1.0 : 1.0;
   float hb1 = (float)fma(sxp, A1, e1) * inv_area, hb2 = (float)fma(sxp, A2, e2) * inv_area;
@@ -180,15 +173,44 @@ __device__ float4 shade_pixel(const FrameParams& P, uint32_t rec, int px, int py
   float dvdx = (px & 1) ? (v - vh) : (vh - v);
   float dudy = (py & 1) ? (u - uv_) : (uv_ - u);
   float dvdy = (py & 1) ? (v - vv_) : (vv_ - v);
-  const TexBinding& tb = P.tex[tex];
-  float4 t = sample_texture(tb, u, v, dudx, dvdx, dudy, dvdy);
+  // ---- texture(colorTex, uv): implicit LOD, then one unified 2-level x 4-tap footprint
+  float W0 = (float)t.w, H0 = (float)t.h;
+  float mx = dudx * W0, my = dvdx * H0;
+  float nx_ = dudy * W0, ny_ = dvdy * H0;
+  float rho2 = fmaxf(fmaf(mx, mx, my * my), fmaf(nx_, nx_, ny_ * ny_));
+  float lambda = fminf(fmaxf(lod_from_rho2(rho2), t.min_lod), t.max_lod);
+  bool linear = ((lambda <= 0.0f) ? (t.filters & 1u) : ((t.filters >> 1) & 1u)) != 0u;
+  int q = (int)t.levels - 1;
+  bool mip_linear = ((t.filters >> 2) & 1u) != 0u;
+  int dn = min(max((int)ceilf(lambda + 0.5f) - 1, 0), q);
+  float lc = fminf(fmaxf(lambda, 0.0f), (float)q);
+  float fl = floorf(lc);
+  int dhi = mip_linear ? (int)fl : dn;
+  float delta = mip_linear ? lc - fl : 0.0f;
+  int dlo = mip_linear ? min(dhi + 1, q) : dn;
+  float us = (fabsf(u) < 8388608.0f) ? u : 0.0f, vs = (fabsf(v) < 8388608.0f) ? v : 0.0f;
+  Taps th = level_taps(t, (uint32_t)dhi, linear, us, vs);
+  Taps tl = level_taps(t, (uint32_t)dlo, linear, us, vs);
+  const uint8_t* tb = t.base;
+  uint32_t h00 = *reinterpret_cast<const uint32_t*>(tb + th.o00), h10 = *reinterpret_cast<const uint32_t*>(tb + th.o10);
+  uint32_t h01 = *reinterpret_cast<const uint32_t*>(tb + th.o01), h11 = *reinterpret_cast<const uint32_t*>(tb + th.o11);
+  uint32_t l00 = *reinterpret_cast<const uint32_t*>(tb + tl.o00), l10 = *reinterpret_cast<const uint32_t*>(tb + tl.o10);
+  uint32_t l01 = *reinterpret_cast<const uint32_t*>(tb + tl.o01), l11 = *reinterpret_cast<const uint32_t*>(tb + tl.o11);
+  float4 tx;
+  tx.x = lerpf(bilerp(h00, h10, h01, h11, 0, th.alpha, th.beta), bilerp(l00, l10, l01, l11, 0, tl.alpha, tl.beta), delta);
+  tx.y = lerpf(bilerp(h00, h10, h01, h11, 1, th.alpha, th.beta), bilerp(l00, l10, l01, l11, 1, tl.alpha, tl.beta), delta);
+  tx.z = lerpf(bilerp(h00, h10, h01, h11, 2, th.alpha, th.beta), bilerp(l00, l10, l01, l11, 2, tl.alpha, tl.beta), delta);
+  tx.w = 1.0f;
   if (TRACE) {  // slots shared with the oracle's trace (tests/tools only)
-    trace[0] = (float)q4[0].z; trace[1] = b1; trace[2] = b2; trace[3] = r; trace[4] = u; trace[5] = v;
-    trace[6] = dudx; trace[7] = dvdx; trace[8] = dudy; trace[9] = dvdy;
-    trace[11] = t.x; trace[12] = t.y; trace[13] = t.z; trace[14] = t.w;
+    trace[0] = (float)hdr.z; trace[1] = b1; trace[2] = b2; trace[3] = r; trace[4] = u; trace[5] = v;
+    trace[6] = dudx; trace[7] = dvdx; trace[8] = dudy; trace[9] = dvdy; trace[10] = lambda;
+    trace[11] = tx.x; trace[12] = tx.y; trace[13] = tx.z;
     trace[26] = hb1; trace[27] = hb2; trace[28] = vb1; trace[29] = vb2; trace[30] = hr; trace[31] = vr;
   }
-  if (kind == PIPE_TEX_IMAGE) return t;  // shaders/tex_image.frag:10-12
+  if (kind == PIPE_TEX_IMAGE) {  // shaders/tex_image.frag:10-12 — the only consumer of texture alpha
+    tx.w = lerpf(bilerp(h00, h10, h01, h11, 3, th.alpha, th.beta), bilerp(l00, l10, l01, l11, 3, tl.alpha, tl.beta), delta);
+    return tx;
+  }
   // shaders/mesh.frag:12-19
   float nx = interp3(s0.w, s2.w, s4.w, b1, b2, r);
   float ny = interp3(s1.x, s3.x, s5.x, b1, b2, r);
@@ -197,9 +219,9 @@ __device__ float4 shade_pixel(const FrameParams& P, uint32_t rec, int px, int py
   float d = fmaf(nz, L[2], fmaf(ny, L[1], nx * L[0]));
   float light = fmaxf(d, 0.1f);
   float sunw = P.scene.sunlight_color[3];
-  float cr = interp3(s1.z, s3.z, s5.z, b1, b2, r) * t.x;
-  float cg = interp3(s1.w, s3.w, s5.w, b1, b2, r) * t.y;
-  float cb = interp3(s2.x, s4.x, s6.x, b1, b2, r) * t.z;
+  cr = cr * tx.x;
+  cg = cg * tx.y;
+  cb = cb * tx.z;
   float4 o;
   o.x = fmaf(cr * light, sunw, cr * P.scene.ambient_color[0]);
   o.y = fmaf(cg * light, sunw, cg * P.scene.ambient_color[1]);
@@ -248,19 +270,63 @@ struct Codec<SVR_COLOR_RGBA8> {
   static __device__ __forceinline__ enc_t encode(float4 c) {
     return un8(c.x) | (un8(c.y) << 8) | (un8(c.z) << 16) | (un8(c.w) << 24);
   }
-  static __device__ __forceinline__ float4 decode(enc_t e) { return unpack_texel(e); }
+  static __device__ __forceinline__ float4 decode(enc_t e) {
+    return make_float4(chan(e, 0), chan(e, 1), chan(e, 2), chan(e, 3));
+  }
 };
 
 // ------------------------------------------------------------------------------------------------
-// Walk one bin (staged through LDS) and update the per-pixel state.
+// One triangle against the wave's four 8x8 blocks.
 //   PEEL == false: keep the fragment with the largest (depth, key)            (opaque visibility)
 //   PEEL == true : keep the depth-passing fragment with the smallest key > last   (next layer)
+template <bool PEEL, bool INSTR>
+__device__ __forceinline__ void raster_triangle(const CovTri& t, uint32_t ri, int ox, int oy, double dpx, double dpy,
+                                                const bool (&pix_ok)[4], uint32_t (&zbits)[4], uint32_t (&keys)[4],
+                                                uint32_t (&recs)[4], const uint32_t (&last)[4], bool count_now,
+                                                uint32_t& n_raster) {
+  double e0 = fma(t.A0, dpx, fma(t.B0, dpy, t.C0));
+  double e1 = fma(t.A1, dpx, fma(t.B1, dpy, t.C1));
+  double e2 = fma(t.A2, dpx, fma(t.B2, dpy, t.C2));
+  double u1 = (t.flags & F_T1) ? 1.0 : 0.0, u2 = (t.flags & F_T2) ? 1.0 : 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int bx = ox + (k & 1) * 8, by = oy + (k >> 1) * 8;
+    if (t.maxx < bx || t.minx > bx + 7 || t.maxy < by || t.miny > by + 7) continue;  // wave-uniform
+    double kx = (double)((k & 1) * 8), ky = (double)((k >> 1) * 8);
+    double f0 = fma(t.A0, kx, fma(t.B0, ky, e0));
+    double f1 = fma(t.A1, kx, fma(t.B1, ky, e1));
+    double f2 = fma(t.A2, kx, fma(t.B2, ky, e2));
+    bool inside = pix_ok[k] && f0 >= 0.0 && f1 >= 0.0 && f2 >= 0.0;
+    if (INSTR && count_now) n_raster += inside ? 1u : 0u;
+    float b1 = (float)(f1 + u1) * t.inv_area, b2 = (float)(f2 + u2) * t.inv_area;
+    float z = fmaf(b2, t.dz2, fmaf(b1, t.dz1, t.z0));
+    z = fminf(fmaxf(z, 0.0f), 1.0f) + 0.0f;
+    uint32_t zb = f2u(z);
+    if (!PEEL) {
+      bool better = inside && (zb > zbits[k] || (zb == zbits[k] && t.key > keys[k]));
+      if (better) {
+        zbits[k] = zb;
+        keys[k] = t.key;
+        recs[k] = ri;
+      }
+    } else {
+      bool take = inside && zb >= zbits[k] && t.key > last[k] && t.key < keys[k];
+      if (take) {
+        keys[k] = t.key;
+        recs[k] = ri;
+      }
+    }
+  }
+}
+
+// Walk one bin (staged through LDS) and update the per-pixel state.
 template <bool PEEL, bool INSTR>
 __device__ __forceinline__ void walk_bin(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, uint32_t bin_base,
                                          uint32_t n, int ox, int oy, int lx, int ly, const bool (&pix_ok)[4],
                                          uint32_t (&zbits)[4], uint32_t (&keys)[4], uint32_t (&recs)[4],
                                          const uint32_t (&last)[4], bool count_now, uint32_t& n_raster) {
   const double dpx = (double)(ox + lx), dpy = (double)(oy + ly);
+  const uint32_t lane = threadIdx.x & 63u;
   for (uint32_t b0 = 0; b0 < n; b0 += BATCH) {
     uint32_t cnt = min((uint32_t)BATCH, n - b0);
     __syncthreads();  // previous batch fully consumed
@@ -270,9 +336,121 @@ __device__ __forceinline__ void walk_bin(const FrameParams& P, uint4* s_cov, uin
       if ((piece & 7u) == 0) s_idx[piece >> 3] = ri;
     }
     __syncthreads();
-    for (uint32_t i = 0; i < cnt; i++) {
-      CovTri t = read_cov(s_cov + i * 8u);
-      if (t.maxx < ox || t.minx > ox + 15 || t.maxy < oy || t.miny > oy + 15) continue;  // wave-uniform
+    // classify the whole batch at once: lane i looks at triangle i's bbox only
+    bool hit = false;
+    if (lane < cnt) {
+      uint4 h = s_cov[lane * 8u];
+      int hminx = (int)(int16_t)(h.x & 0xffffu), hminy = (int)(int16_t)(h.x >> 16);
+      int hmaxx = (int)(int16_t)(h.y & 0xffffu), hmaxy = (int)(int16_t)(h.y >> 16);
+      hit = !(hmaxx < ox || hminx > ox + 15 || hmaxy < oy || hminy > oy + 15);
+    }
+    unsigned long long todo = __ballot(hit);
+    if (!todo) continue;
+    // accepted triangles only, the next one's LDS reads in flight while this one is rasterised
+    int i = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    CovTri cur = read_cov(s_cov + (uint32_t)i * 8u);
+    uint32_t cri = s_idx[i];
+    for (;;) {
+      bool more = todo != 0;
+      int ni = more ? __ffsll((long long)todo) - 1 : i;
+      todo &= todo - 1;
+      CovTri nxt = read_cov(s_cov + (uint32_t)ni * 8u);
+      uint32_t nri = s_idx[ni];
+      raster_triangle<PEEL, INSTR>(cur, cri, ox, oy, dpx, dpy, pix_ok, zbits, keys, recs, last, count_now, n_raster);
+      if (!more) break;
+      cur = nxt;
+      cri = nri;
+      i = ni;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Transparent pass, ordered form.  Blending is order dependent (the target rounds after every
+// blend), so fragments must reach each pixel in submission order.  The tile's transparent bin is
+// sorted by submission key once (bitonic sort in LDS, written back in place), then walked once;
+// depth-passing fragments are compacted into a per-wave LDS queue with __ballot + prefix popcount,
+// shaded 64 at a time by whichever lanes are free (full lane efficiency however small the
+// triangles are) and blended into the wave's LDS colour block.  Several fragments of one pixel can
+// sit in the same group of 64: they are applied in queue order by electing, per pixel, the lowest
+// pending lane with ds_min (the result of a min does not depend on lane execution order).
+constexpr uint32_t SORT_CAP = 2048;           // bins above this fall back to per-layer peeling
+constexpr uint32_t QUEUE_CAP = 320;           // < 64 carried over + up to 256 new per triangle
+constexpr uint32_t WAVE_C_BYTES = 256 * 8 + QUEUE_CAP * 8 + 256 * 4;  // colour | queue | election slots
+
+template <int FMT, bool INSTR>
+__device__ __forceinline__ void flush_fragments(const FrameParams& P, typename Codec<FMT>::enc_t* col, uint2* q,
+                                                uint32_t* slot, uint32_t& qn, int ox, int oy, uint32_t lane,
+                                                uint32_t& n_shaded) {
+  typedef Codec<FMT> CD;
+  uint32_t cnt = min(qn, 64u);
+  bool act = lane < cnt;
+  uint2 e = q[act ? lane : 0u];
+  uint32_t pix = e.x, rec = e.y;
+  int k = (int)(pix >> 6), l = (int)(pix & 63u);
+  int px = ox + (k & 1) * 8 + (l & 7), py = oy + (k >> 1) * 8 + (l >> 3);
+  float4 src = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (act) {
+    src = shade_pixel<false>(P, rec, px, py, nullptr);
+    if (INSTR) n_shaded++;
+  }
+  bool pending = act;
+  while (__ballot(pending)) {
+    if (pending) atomicMin(&slot[pix], lane);
+    if (pending && slot[pix] == lane) {
+      float4 dst = CD::decode(col[pix]);
+      // enable_blending_additive: rgb = src*ONE + dst*DST_ALPHA, a = src*ONE + dst*ZERO
+      float4 o = make_float4(fmaf(dst.x, dst.w, src.x), fmaf(dst.y, dst.w, src.y), fmaf(dst.z, dst.w, src.z), src.w);
+      if (INSTR && P.trace_buf && px == P.trace_x && py == P.trace_y) {
+        (void)shade_pixel<true>(P, rec, px, py, P.trace_buf);
+        float* tb = P.trace_buf;
+        tb[32] = dst.x; tb[33] = dst.y; tb[34] = dst.z; tb[35] = dst.w;
+        tb[36] = o.x; tb[37] = o.y; tb[38] = o.z; tb[39] = o.w;
+      }
+      col[pix] = CD::encode(o);
+      slot[pix] = 0xffffffffu;
+      pending = false;
+    }
+  }
+  uint32_t rest = qn - cnt;
+  for (uint32_t j = lane; j < rest; j += 64u) {  // lock-step: every read of a step precedes its writes
+    uint2 v = q[cnt + j];
+    q[j] = v;
+  }
+  qn = rest;
+}
+
+template <int FMT, bool INSTR>
+__device__ __forceinline__ void walk_ordered(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, uint32_t bin_base,
+                                             uint32_t n, int ox, int oy, int lx, int ly, const bool (&pix_ok)[4],
+                                             const uint32_t (&zbits)[4], typename Codec<FMT>::enc_t* col, uint2* q,
+                                             uint32_t* slot, uint32_t& n_raster, uint32_t& n_shaded) {
+  const double dpx = (double)(ox + lx), dpy = (double)(oy + ly);
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t qn = 0;
+  for (uint32_t b0 = 0; b0 < n; b0 += BATCH) {
+    uint32_t cnt = min((uint32_t)BATCH, n - b0);
+    __syncthreads();
+    for (uint32_t piece = threadIdx.x; piece < cnt * 8u; piece += 256u) {
+      uint32_t ri = P.bins[bin_base + b0 + (piece >> 3)];
+      s_cov[piece] = reinterpret_cast<const uint4*>(P.recs + ri)[piece & 7u];
+      if ((piece & 7u) == 0) s_idx[piece >> 3] = ri;
+    }
+    __syncthreads();
+    bool hit = false;
+    if (lane < cnt) {
+      uint4 h = s_cov[lane * 8u];
+      int hminx = (int)(int16_t)(h.x & 0xffffu), hminy = (int)(int16_t)(h.x >> 16);
+      int hmaxx = (int)(int16_t)(h.y & 0xffffu), hmaxy = (int)(int16_t)(h.y >> 16);
+      hit = !(hmaxx < ox || hminx > ox + 15 || hmaxy < oy || hminy > oy + 15);
+    }
+    unsigned long long todo = __ballot(hit);
+    while (todo) {  // ascending bit order == submission order inside the sorted batch
+      int i = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      CovTri t = read_cov(s_cov + (uint32_t)i * 8u);
       uint32_t ri = s_idx[i];
       double e0 = fma(t.A0, dpx, fma(t.B0, dpy, t.C0));
       double e1 = fma(t.A1, dpx, fma(t.B1, dpy, t.C1));
@@ -287,43 +465,71 @@ __device__ __forceinline__ void walk_bin(const FrameParams& P, uint4* s_cov, uin
         double f1 = fma(t.A1, kx, fma(t.B1, ky, e1));
         double f2 = fma(t.A2, kx, fma(t.B2, ky, e2));
         bool inside = pix_ok[k] && f0 >= 0.0 && f1 >= 0.0 && f2 >= 0.0;
-        if (INSTR && count_now) n_raster += inside ? 1u : 0u;
+        if (INSTR) n_raster += inside ? 1u : 0u;
         float b1 = (float)(f1 + u1) * t.inv_area, b2 = (float)(f2 + u2) * t.inv_area;
         float z = fmaf(b2, t.dz2, fmaf(b1, t.dz1, t.z0));
         z = fminf(fmaxf(z, 0.0f), 1.0f) + 0.0f;
-        uint32_t zb = f2u(z);
-        if (!PEEL) {
-          bool better = inside && (zb > zbits[k] || (zb == zbits[k] && t.key > keys[k]));
-          if (better) {
-            zbits[k] = zb;
-            keys[k] = t.key;
-            recs[k] = ri;
-          }
-        } else {
-          bool take = inside && zb >= zbits[k] && t.key > last[k] && t.key < keys[k];
-          if (take) {
-            keys[k] = t.key;
-            recs[k] = ri;
+        bool pass = inside && f2u(z) >= zbits[k];  // depth test GREATER_OR_EQUAL, no depth write
+        unsigned long long m = __ballot(pass);
+        if (m) {
+          if (pass) q[qn + (uint32_t)__popcll(m & below)] = make_uint2((uint32_t)k * 64u + lane, ri);
+          qn += (uint32_t)__popcll(m);
+        }
+      }
+      while (qn >= 64u) flush_fragments<FMT, INSTR>(P, col, q, slot, qn, ox, oy, lane, n_shaded);
+    }
+  }
+  while (qn) flush_fragments<FMT, INSTR>(P, col, q, slot, qn, ox, oy, lane, n_shaded);
+}
+
+// bitonic sort of the bin's (key << 32 | record) words by all 256 threads, written back in place
+__device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned long long* s, uint32_t bin_base, uint32_t n) {
+  uint32_t np = 64;
+  while (np < n) np <<= 1;
+  for (uint32_t i = threadIdx.x; i < np; i += 256u) {
+    unsigned long long v = ~0ull;
+    if (i < n) {
+      uint32_t ri = P.bins[bin_base + i];
+      v = ((unsigned long long)P.recs[ri].key << 32) | ri;
+    }
+    s[i] = v;
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= np; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = threadIdx.x; i < np; i += 256u) {
+        uint32_t x = i ^ j;
+        if (x > i) {
+          unsigned long long a = s[i], b = s[x];
+          bool asc = (i & k) == 0;
+          if ((a > b) == asc) {
+            s[i] = b;
+            s[x] = a;
           }
         }
       }
+      __syncthreads();
     }
   }
+  for (uint32_t i = threadIdx.x; i < n; i += 256u) P.bins[bin_base + i] = (uint32_t)s[i];
+  __threadfence_block();
+  __syncthreads();
 }
 
 template <int FMT, bool INSTR>
-__global__ __launch_bounds__(256) void tile_kernel(FrameParams P) {
+__global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
   typedef Codec<FMT> CD;
   typedef typename CD::enc_t enc_t;
   __shared__ uint4 s_cov[BATCH * 8];
   __shared__ uint32_t s_idx[BATCH];
+  __shared__ __attribute__((aligned(16))) unsigned char s_c[4 * WAVE_C_BYTES];  // phase C only (22 KiB)
+  static_assert(4 * WAVE_C_BYTES >= SORT_CAP * 8, "sort scratch aliases the phase-C block");
 
   if (P.counters->overflow) return;  // pass is void; the host grows its buffers and replays it
-  // XCD-aware mapping: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), give each XCD one
-  // contiguous span of tiles so its L2 keeps that screen region's records and texels.
-  uint32_t per = (P.n_tiles + 7u) >> 3;
-  uint32_t tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-  if (tile >= P.n_tiles) return;
+  // Workgroups are dispatched in blockIdx order: walk the tiles heaviest class first (scan_kernel's
+  // tile_order).  Tiles are dealt round-robin over the 8 XCDs; a contiguous span per XCD was tried
+  // and loses: the heavy rows of the frame all land on one XCD and the other seven idle.
+  uint32_t tile = P.tile_order[blockIdx.x];
   uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
   uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   int ox = (int)(P.sx + tx * TILE + (wave & 1u) * 16u), oy = (int)(P.sy + ty * TILE + (wave >> 1) * 16u);
@@ -342,11 +548,14 @@ __global__ __launch_bounds__(256) void tile_kernel(FrameParams P) {
     zero4[k] = 0u;
   }
   uint32_t n_raster = 0, n_shaded = 0;
+  long long stamp[5] = {0, 0, 0, 0, 0};  // instrumented variant only: shader-clock stamps per phase
+  if (INSTR) stamp[0] = clock64();
 
   // ---- phase A: opaque visibility
   uint32_t n_op = P.tile_count[tile], n_tr = P.tile_count[P.n_tiles + tile];
   if (n_op) walk_bin<false, INSTR>(P, s_cov, s_idx, P.tile_offset[tile], n_op, ox, oy, lx, ly, pix_ok, zbits, keys, recs, zero4, true, n_raster);
 
+  if (INSTR) stamp[1] = clock64();
   // ---- phase B: shade visible pixels once
   enc_t enc[4];
   bool dirty[4];
@@ -364,8 +573,32 @@ __global__ __launch_bounds__(256) void tile_kernel(FrameParams P) {
     }
   }
 
-  // ---- phase C: transparent layers in submission order
-  if (n_tr) {
+  if (INSTR) stamp[2] = clock64();
+  // ---- phase C: transparent fragments in submission order
+  if (n_tr && n_tr <= SORT_CAP) {
+    uint32_t tbase = P.tile_offset[P.n_tiles + tile];
+    sort_bin_by_key(P, reinterpret_cast<unsigned long long*>(s_c), tbase, n_tr);
+    unsigned char* mine = s_c + wave * WAVE_C_BYTES;
+    enc_t* col = reinterpret_cast<enc_t*>(mine);
+    uint2* q = reinterpret_cast<uint2*>(mine + 256 * 8);
+    uint32_t* slot = reinterpret_cast<uint32_t*>(mine + 256 * 8 + QUEUE_CAP * 8);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
+      size_t p = (size_t)py * P.W + (size_t)px;
+      enc_t c = enc[k];
+      if (!dirty[k] && pix_ok[k]) c = reinterpret_cast<const enc_t*>(P.color)[p];  // colour loadOp LOAD
+      col[k * 64 + (int)lane] = c;
+      slot[k * 64 + (int)lane] = 0xffffffffu;
+    }
+    walk_ordered<FMT, INSTR>(P, s_cov, s_idx, tbase, n_tr, ox, oy, lx, ly, pix_ok, zbits, col, q, slot, n_raster, n_shaded);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      enc[k] = col[k * 64 + (int)lane];
+      dirty[k] = pix_ok[k];
+    }
+  } else if (n_tr) {
+    // bins too large to sort in LDS: peel one layer per pass (cost = layers x bin, any size)
     uint32_t last[4] = {0u, 0u, 0u, 0u};
     bool first = true;
     for (;;) {
@@ -403,6 +636,7 @@ __global__ __launch_bounds__(256) void tile_kernel(FrameParams P) {
     }
   }
 
+  if (INSTR) stamp[3] = clock64();
   // ---- phase D: write back
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -413,6 +647,10 @@ __global__ __launch_bounds__(256) void tile_kernel(FrameParams P) {
     if (dirty[k]) reinterpret_cast<enc_t*>(P.color)[p] = enc[k];
   }
   if (INSTR) {
+    stamp[4] = clock64();
+    if (P.tile_cycles && threadIdx.x == 0) {
+      for (int k = 0; k < 4; k++) P.tile_cycles[tile * 4u + k] = (uint32_t)(stamp[k + 1] - stamp[k]);
+    }
     for (int off = 32; off > 0; off >>= 1) {
       n_raster += __shfl_down(n_raster, off);
       n_shaded += __shfl_down(n_shaded, off);
@@ -425,8 +663,7 @@ __global__ __launch_bounds__(256) void tile_kernel(FrameParams P) {
 }
 
 void launch_tiles(const FrameParams& P, int color_format, bool count_fragments, hipStream_t s) {
-  uint32_t per = (P.n_tiles + 7u) >> 3;
-  dim3 grid(per * 8u), block(256);
+  dim3 grid(P.n_tiles), block(256);
   if (color_format == SVR_COLOR_RGBA16F) {
     if (count_fragments)
       hipLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA16F, true>), grid, block, 0, s, P);

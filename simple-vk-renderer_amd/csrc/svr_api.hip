@@ -65,7 +65,8 @@ struct MeshRes {
 struct ImageRes {
   uint8_t* base = nullptr;
   uint32_t w = 0, h = 0, levels = 0;
-  uint32_t off[16] = {0};
+  uint32_t lw = 0, lh = 0;  // log2 of the power-of-two padded extent the mip layout is computed from
+  uint32_t off[16] = {0};   // = mip_offset(lw, lh, level)
   bool alive = false;
 };
 struct MaterialRes {
@@ -139,7 +140,7 @@ struct SvrContext {
   FrameParams last{};        // parameters of that pass, for replay
   bool instrument = false;
   int trace_x = -1, trace_y = -1;
-  DevBuf d_trace;
+  DevBuf d_trace, d_tile_cycles;
   SvrStats stats{};
 };
 
@@ -162,14 +163,12 @@ ImageRes* get_image(SvrContext* ctx, SvrImage h) {
 TexBinding make_binding(const ImageRes& im, const SvrSamplerDesc& s) {
   TexBinding tb;
   std::memset(&tb, 0, sizeof(tb));
+  uint32_t filters = (uint32_t)s.mag_filter | ((uint32_t)s.min_filter << 1) | ((uint32_t)s.mipmap_mode << 2);
   tb.base = im.base;
-  tb.w = im.w;
-  tb.h = im.h;
-  tb.levels = im.levels;
-  tb.filters = (uint32_t)s.mag_filter | ((uint32_t)s.min_filter << 1) | ((uint32_t)s.mipmap_mode << 2);
+  tb.wh = im.w | (im.h << 16);
+  tb.info = im.lw | (im.lh << 8) | (im.levels << 16) | (filters << 24);
   tb.min_lod = s.min_lod;
   tb.max_lod = s.max_lod;
-  for (int l = 0; l < 16; l++) tb.level_offset[l] = im.off[l];
   return tb;
 }
 
@@ -305,7 +304,7 @@ int enqueue_pass(SvrContext* ctx, const FrameParams& P) {
 int bind_pass_buffers(SvrContext* ctx, FrameParams& P) {
   if (int e = ctx->d_recs.ensure(((size_t)P.n_tris + ctx->extra_cap) * sizeof(TriRec))) return e;
   if (int e = ctx->d_clipq.ensure((size_t)ctx->clip_cap * sizeof(ClipItem))) return e;
-  if (int e = ctx->d_tiles.ensure((size_t)P.n_tiles * 6 * sizeof(uint32_t))) return e;
+  if (int e = ctx->d_tiles.ensure((size_t)P.n_tiles * 7 * sizeof(uint32_t))) return e;
   if (int e = ctx->d_bins.ensure((size_t)ctx->bin_cap * sizeof(uint32_t))) return e;
   if (int e = ctx->d_counters.ensure(sizeof(Counters))) return e;
   P.recs = (TriRec*)ctx->d_recs.p;
@@ -315,6 +314,7 @@ int bind_pass_buffers(SvrContext* ctx, FrameParams& P) {
   P.tile_count = (uint32_t*)ctx->d_tiles.p;
   P.tile_cursor = P.tile_count + (size_t)P.n_tiles * 2;
   P.tile_offset = P.tile_count + (size_t)P.n_tiles * 4;
+  P.tile_order = P.tile_count + (size_t)P.n_tiles * 6;
   P.bins = (uint32_t*)ctx->d_bins.p;
   P.bin_cap = ctx->bin_cap;
   P.counters = (Counters*)ctx->d_counters.p;
@@ -389,6 +389,11 @@ int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& 
   P.trace_x = ctx->trace_x;
   P.trace_y = ctx->trace_y;
   P.trace_buf = (ctx->instrument && ctx->trace_x >= 0) ? (float*)ctx->d_trace.p : nullptr;
+  P.tile_cycles = nullptr;
+  if (ctx->instrument) {
+    if (int e = ctx->d_tile_cycles.ensure((size_t)P.n_tiles * 16)) return e;
+    P.tile_cycles = (uint32_t*)ctx->d_tile_cycles.p;
+  }
   if (scene) P.scene = *scene;
   // capacities: generous first guesses; overflow -> replay (finish_pending)
   ctx->clip_cap = std::max<uint32_t>(ctx->clip_cap, std::max<uint32_t>(65536u, P.n_tris / 4u));
@@ -484,7 +489,7 @@ void svr_destroy(SvrContext* ctx) {
   for (auto& im : ctx->images)
     if (im.base) (void)hipFree(im.base);
   DevBuf* bufs[] = {&ctx->tex_table, &ctx->d_draws, &ctx->d_chunks, &ctx->d_recs, &ctx->d_clipq,
-                    &ctx->d_tiles,   &ctx->d_bins,  &ctx->d_counters, &ctx->d_cvt, &ctx->d_trace};
+                    &ctx->d_tiles,   &ctx->d_bins,  &ctx->d_counters, &ctx->d_cvt, &ctx->d_trace, &ctx->d_tile_cycles};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < SvrContext::RING; i++) {
     if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
@@ -584,16 +589,16 @@ int svr_create_image(SvrContext* ctx, const void* rgba8, uint32_t width, uint32_
       im.levels++;
     }
   }
-  size_t total = 0;
+  // Mip levels are laid out as if the image were padded to 2^lw x 2^lh, so a shader derives a
+  // level's offset from (lw, lh, level) alone (svr::mip_offset) and needs no per-image table.
+  while ((1u << im.lw) < width) im.lw++;
+  while ((1u << im.lh) < height) im.lh++;
+  for (uint32_t l = 0; l < im.levels; l++) im.off[l] = mip_offset(im.lw, im.lh, l);
   uint32_t lw = width, lh = height;
-  for (uint32_t l = 0; l < im.levels; l++) {
-    im.off[l] = (uint32_t)total;
-    total += ((size_t)lw * lh * 4 + 255) & ~(size_t)255;
-    lw = std::max(1u, lw >> 1);
-    lh = std::max(1u, lh >> 1);
-  }
-  if (total > 0xffffffffull) return fail(SVR_ERR_UNSUPPORTED, "svr_create_image: image larger than 4 GiB");
-  HIPCHK(hipMalloc((void**)&im.base, total));
+  size_t total = (size_t)mip_offset(im.lw, im.lh, im.levels - 1) +
+                 (size_t)std::max(1u, width >> (im.levels - 1)) * std::max(1u, height >> (im.levels - 1)) * 4;
+  if (im.lw + im.lh > 28) return fail(SVR_ERR_UNSUPPORTED, "svr_create_image: image larger than 1 GiB");
+  HIPCHK(hipMalloc((void**)&im.base, std::max<size_t>(total, 256)));
   hipError_t r = hipMemcpy(im.base, rgba8, (size_t)width * height * 4, hipMemcpyHostToDevice);
   if (r != hipSuccess) {
     (void)hipFree(im.base);
@@ -910,6 +915,30 @@ int svr_debug_read_trace(SvrContext* ctx, float out[64]) {
   if (int e = finish_pending(ctx)) return e;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(out, ctx->d_trace.p, 64 * sizeof(float), hipMemcpyDeviceToHost));
+  return SVR_OK;
+}
+
+int svr_debug_read_bins(SvrContext* ctx, uint32_t* counts, size_t capacity, uint32_t* n_tiles) {
+  if (!ctx || !n_tiles) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_debug_read_bins: null argument");
+  if (int e = use_device(ctx)) return e;
+  if (int e = finish_pending(ctx)) return e;
+  *n_tiles = ctx->last.n_tiles;
+  if (!counts) return SVR_OK;
+  if (capacity < 2 * (size_t)ctx->last.n_tiles || !ctx->last.tile_count)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_debug_read_bins: buffer too small or no pass yet");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(counts, ctx->last.tile_count, 2 * (size_t)ctx->last.n_tiles * 4, hipMemcpyDeviceToHost));
+  return SVR_OK;
+}
+
+int svr_debug_read_tile_cycles(SvrContext* ctx, uint32_t* cycles, size_t capacity) {
+  if (!ctx || !cycles) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_debug_read_tile_cycles: null argument");
+  if (int e = use_device(ctx)) return e;
+  if (int e = finish_pending(ctx)) return e;
+  if (!ctx->last.tile_cycles || capacity < 4 * (size_t)ctx->last.n_tiles)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_debug_read_tile_cycles: last pass was not instrumented or buffer too small");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(cycles, ctx->last.tile_cycles, 16 * (size_t)ctx->last.n_tiles, hipMemcpyDeviceToHost));
   return SVR_OK;
 }
 

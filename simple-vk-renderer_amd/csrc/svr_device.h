@@ -43,16 +43,28 @@ struct WaveChunk {
   uint32_t first_tri;
 };
 
-// Texture + sampler as the fragment stage sees them (combined image sampler), 128 bytes.
+// Texture + sampler as the fragment stage sees them (combined image sampler).  24 meaningful bytes
+// so the setup kernel can copy it into every TriRec: shading then needs no descriptor fetch.
+// Mip level l of an image lives at byte offset mip_offset(lw, lh, l) from base (levels are laid
+// out as if the image were padded to 2^lw x 2^lh, so the offset is a closed form), row pitch =
+// the level's true width max(w >> l, 1).
 struct TexBinding {
-  const uint8_t* base;      // RGBA8 texels, all mip levels, level l at base + level_offset[l]
-  uint32_t w, h, levels;
-  uint32_t filters;         // mag | min << 1 | mipmap_mode << 2
+  const uint8_t* base;      // RGBA8 texels of level 0
+  uint32_t wh;              // w | h << 16   (extent <= 16384 each)
+  uint32_t info;            // lw | lh << 8 | levels << 16 | filters << 24; filters = mag | min<<1 | mip<<2
   float min_lod, max_lod;
-  uint32_t level_offset[16];
-  uint32_t pad[8];
+  uint32_t pad[2];
 };
-static_assert(sizeof(TexBinding) == 128, "TexBinding layout");
+static_assert(sizeof(TexBinding) == 32, "TexBinding layout");
+
+__host__ __device__ inline uint32_t mip_offset(uint32_t lw, uint32_t lh, uint32_t level) {
+  uint32_t off = 0;
+  for (uint32_t k = 0; k < level; k++) {
+    uint32_t a = lw > k ? lw - k : 0u, b = lh > k ? lh - k : 0u;
+    off += 4u << (a + b);
+  }
+  return off;
+}
 
 // A set-up triangle, 256 bytes: first half is all the coverage/depth loop reads, second half only
 // the winners' shading reads.  Edge functions are evaluated at integer pixel indices (px,py):
@@ -64,16 +76,17 @@ struct TriRec {
   uint32_t flags;
   float z0, dz1, dz2, inv_area;
   double A[3], B[3], C[3];
-  uint32_t tex;
-  float zmax;
-  uint32_t pad1[4];
+  const uint8_t* tex_base;         // the draw's TexBinding, copied in (offset 104)
+  uint32_t tex_wh, tex_info;
+  float tex_min_lod, tex_max_lod;
   // ---- shading half
   float q0, dq1, dq2;              // 1/w
   float a0[8], da1[8], da2[8];     // varyings pre-divided by w: normal.xyz, color.rgb, uv
   float pad2[5];
 };
 static_assert(sizeof(TriRec) == 256, "TriRec layout");
-static_assert(offsetof(TriRec, A) == 32 && offsetof(TriRec, q0) == 128, "TriRec layout");
+static_assert(offsetof(TriRec, A) == 32 && offsetof(TriRec, tex_base) == 104 && offsetof(TriRec, tex_wh) == 112 &&
+                  offsetof(TriRec, q0) == 128, "TriRec layout");
 
 struct ClipItem {
   uint32_t draw;
@@ -112,6 +125,7 @@ struct FrameParams {
   uint32_t* tile_count;           // [2*n_tiles]: opaque bins then transparent bins
   uint32_t* tile_offset;          // [2*n_tiles]
   uint32_t* tile_cursor;          // [2*n_tiles]
+  uint32_t* tile_order;           // [n_tiles] launch order of the tile kernel, heaviest first
   uint32_t* bins;
   uint32_t bin_cap;
   Counters* counters;
@@ -119,6 +133,7 @@ struct FrameParams {
   uint32_t instrument;            // count fragments/triangles with device atomics (not in timed runs)
   int trace_x, trace_y;           // instrumented passes only: dump the shading of this pixel
   float* trace_buf;               // 64 floats or NULL
+  uint32_t* tile_cycles;          // instrumented passes: [n_tiles][4] shader-clock cycles of phases A..D
   SvrSceneData scene;
 };
 
@@ -244,7 +259,7 @@ __device__ __forceinline__ void store_invalid(TriRec* rec) {
 // dropped (zero area or no pixel centre inside the scissor).
 __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, const VOut* v1, const VOut* v2,
                                       ScreenV s0, ScreenV s1, ScreenV s2, uint32_t key, uint32_t draw_flags,
-                                      uint32_t tex, TriRec* out) {
+                                      const TexBinding& tex, TriRec* out) {
   int X0 = __float2int_rn(s0.xs * 256.0f), Y0 = __float2int_rn(s0.ys * 256.0f);
   int X1 = __float2int_rn(s1.xs * 256.0f), Y1 = __float2int_rn(s1.ys * 256.0f);
   int X2 = __float2int_rn(s2.xs * 256.0f), Y2 = __float2int_rn(s2.ys * 256.0f);
@@ -292,7 +307,6 @@ __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, cons
   h.y = ((uint32_t)(uint16_t)pmaxx) | ((uint32_t)(uint16_t)pmaxy << 16);
   h.z = key;
   h.w = flags;
-  float zmax = fmaxf(s0.zs, fmaxf(s1.zs, s2.zs));
   float4 zrow = make_float4(s0.zs, s1.zs - s0.zs, s2.zs - s0.zs, inv_area);
   q[0] = h;
   reinterpret_cast<float4*>(out)[1] = zrow;
@@ -302,8 +316,8 @@ __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, cons
   dq[4] = make_double2(B[1], B[2]);
   dq[5] = make_double2(C[0], C[1]);
   out->C[2] = C[2];
-  out->tex = tex;
-  out->zmax = zmax;
+  out->tex_base = tex.base;
+  q[7] = make_uint4(tex.wh, tex.info, f2u(tex.min_lod), f2u(tex.max_lod));
   // shading half
   float* f = reinterpret_cast<float*>(out) + 32;
   float rw0 = s0.rw, rw1 = s1.rw, rw2 = s2.rw;

@@ -251,6 +251,28 @@ def random_soup(lib, w=160, h=96, n_tris=600, seed=7, transparent_every=5, color
     return rig.finish()
 
 
+def transparent_stack(lib, n_layers, size=48, jitter=0.0, seed=21):
+    """n_layers small transparent quads stacked on the same pixels (one 32x32 tile holds 2*n_layers
+    triangles): deep in-order blending.  More than 1024 layers exceeds the tile kernel's LDS sort
+    capacity and takes its per-layer fallback."""
+    rng = np.random.default_rng(seed)
+    rig = Rig(lib, size, size, background=(0.0, 0.0, 0.0, 1))
+    verts, idx = [], []
+    for i in range(n_layers):
+        cx, cy = rng.uniform(-jitter, jitter, 2)
+        x0, y0 = -0.62 + cx, -0.55 + cy
+        c = (0.004 + 0.003 * (i % 5), 0.002 * (i % 3), 0.001 * (i % 7), 1)
+        verts.append(clip_quad(x0, y0, x0 + 0.5, y0 + 0.45, 0.3 + 0.4 * (i % 11) / 11.0, color=c))
+        idx.append(QUAD_IDX + 4 * i)
+    back = clip_quad(-1, -1, 0.1, 1, 0.5, color=(0.2, 0.2, 0.2, 1))  # opaque: hides the layers behind z=.5 on the left
+    mesh = rig.r.upload_mesh(np.concatenate(idx), np.concatenate(verts))
+    mb = rig.r.upload_mesh(QUAD_IDX, back)
+    mo, mt = rig.material(), rig.material(transparent=True)
+    rig.draw(identity_scene(ambient=0.0, sun=(0, 1, 0, 1)), [render_object(mb, mo, 0, 6)],
+             [render_object(mesh, mt, 0, 6 * n_layers)])
+    return rig.finish()
+
+
 def ragged_draws(lib, size=48):
     """index_count not a multiple of 3, zero-length draws, an empty opaque list entry order."""
     rig = Rig(lib, size, size)
@@ -291,6 +313,9 @@ SCENARIOS = {
     "soup_opaque_only": lambda lib: random_soup(lib, seed=3, transparent_every=0, n_tris=900),
     "soup_scissor": lambda lib: random_soup(lib, seed=5, scissor=(13, 21, 101, 37)),
     "soup_odd_size": lambda lib: random_soup(lib, w=67, h=35, seed=9, n_tris=300),
+    "transparent_stack_40": lambda lib: transparent_stack(lib, 40, jitter=0.05),
+    "transparent_stack_700": lambda lib: transparent_stack(lib, 700, jitter=0.02),
+    "transparent_stack_1300_fallback": lambda lib: transparent_stack(lib, 1300),
     "ragged": ragged_draws,
     "empty": empty_frame,
 }

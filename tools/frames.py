@@ -1,0 +1,94 @@
+"""Developer tool: render N frames of a BASELINE config on the GPU (a short, quiet target for
+rocprofv3) and optionally print the per-tile bin histogram.
+
+    python tools/frames.py --frames 20 --hist
+    rocprofv3 --pmc SQ_WAVES ... -- python tools/frames.py --frames 5
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--lod", type=int, default=1)
+    ap.add_argument("--tex-size", type=int, default=1024)
+    ap.add_argument("--instances", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=20)
+    ap.add_argument("--hist", action="store_true")
+    args = ap.parse_args()
+    pkg = g.load_package()
+    hip = pkg.load_product_library()
+    S, A = pkg.scenes, pkg.abi
+    sc = S.sponza_like(lod=args.lod, tex_size=args.tex_size)
+    r = hip.create(args.width, args.height)
+    handles = sc.upload(r)
+    inst = S.config5_instances() if args.instances == 16 else None
+    opaque, transparent = sc.render_objects(handles, instance_transforms=inst)
+    pos, pitch, yaw = S.config5_camera() if args.instances == 16 else S.config3_camera()
+    scene = S.scene_data_struct(pos, pitch, yaw, args.width, args.height)
+    r.set_option(A.OPT_KERNEL_TIMING, 1)
+    for _ in range(3):
+        r.clear_color((1, 1, 1, 1))
+        r.draw_geometry(scene, opaque, transparent)
+    r.sync()
+    r.set_option(A.OPT_KERNEL_TIMING, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.frames):
+        r.clear_color((1, 1, 1, 1))
+        r.draw_geometry(scene, opaque, transparent)
+    r.sync()
+    dt = (time.perf_counter() - t0) / args.frames
+    st = r.get_stats()
+    print(f"{args.width}x{args.height} x{args.instances}: {dt * 1e3:.3f} ms/frame wall; geometry {st.geometry_ms:.3f} "
+          f"binning {st.binning_ms:.3f} tile {st.tile_ms:.3f} ms; host record {st.mesh_draw_time:.3f} ms; "
+          f"bin entries {st.bin_entries}")
+    if args.hist:
+        op, tr = r.read_bins()
+        for name, c in (("opaque", op), ("transparent", tr)):
+            qs = np.percentile(c, [0, 25, 50, 75, 90, 99, 100]).astype(int).tolist()
+            print(f"  {name}: tiles {c.size} sum {int(c.sum())} mean {c.mean():.1f} nonempty {(c > 0).sum()} "
+                  f"percentiles(0,25,50,75,90,99,100) {qs}")
+        tx = (args.width + 31) // 32
+        rows = op.reshape(-1, tx).sum(axis=1)
+        print("  opaque entries per tile row:", rows.tolist())
+        # one instrumented frame: shader-clock cycles per tile and phase
+        r.set_option(A.OPT_COUNT_FRAGMENTS, 1)
+        r.clear_color((1, 1, 1, 1))
+        r.draw_geometry(scene, opaque, transparent)
+        r.sync()
+        cyc = r.read_tile_cycles().astype(np.float64)
+        tot = cyc.sum(axis=1)
+        print("  tile cycles (instrumented variant): phase sums A/B/C/D (Mcycles):",
+              [round(float(v) / 1e6, 1) for v in cyc.sum(axis=0)])
+        print("  per-tile total cycles percentiles(0,50,90,99,100):",
+              np.percentile(tot, [0, 50, 90, 99, 100]).astype(int).tolist(), "sum", int(tot.sum()))
+        for lo, hi in ((0, 4), (4, 16), (16, 64), (64, 256), (256, 1 << 30)):
+            m = (op >= lo) & (op < hi)
+            if m.any():
+                print(f"    tiles with {lo}<=n<{hi}: {int(m.sum())} tiles, mean cycles A {cyc[m, 0].mean():.0f} B {cyc[m, 1].mean():.0f} "
+                      f"C {cyc[m, 2].mean():.0f} D {cyc[m, 3].mean():.0f}; mean n {op[m].mean():.1f}")
+        top = np.argsort(-tot)[:12]
+        print("    slowest tiles (tile, x, y, n_opaque, n_transparent, cycles A, B, C, D):")
+        for t in top:
+            print(f"      {int(t):6d} {int(t % tx):4d} {int(t // tx):4d} {int(op[t]):6d} {int(tr[t]):6d} "
+                  f"{int(cyc[t, 0]):9d} {int(cyc[t, 1]):9d} {int(cyc[t, 2]):9d} {int(cyc[t, 3]):9d}")
+        n = op.astype(np.float64)
+        big = op >= 64
+        if big.sum() > 4:
+            coef = np.polyfit(n[big], cyc[big, 0], 1)
+            print(f"    phase A fit on heavy tiles: {coef[0]:.1f} cycles/triangle + {coef[1]:.0f}")
+    r.close()
+
+
+if __name__ == "__main__":
+    main()
