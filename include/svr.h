@@ -215,8 +215,12 @@ int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint
  * SVR_OPT_COUNT_FRAGMENTS: 1 = count rasterized/shaded fragments and binned triangles with device
  * atomics (instrumented kernels; keep 0 for timed runs).
  * SVR_OPT_KERNEL_TIMING: 1 = record hipEvents between the kernels of every pass and average them
- * into SvrStats.{geometry,binning,tile}_ms; setting it (to 0 or 1) resets the averages. */
-enum SvrOption { SVR_OPT_COUNT_FRAGMENTS = 1, SVR_OPT_KERNEL_TIMING = 2 };
+ * into SvrStats.{geometry,binning,tile}_ms; setting it (to 0 or 1) resets the averages.
+ * SVR_OPT_TILE_CYCLES: 1 = every tile workgroup records the shader-clock cycles of its phases
+ * (svr_debug_read_tile_cycles); five s_memtime reads per tile, off by default.
+ * SVR_OPT_TUNING: bit mask that switches individual optimisations OFF (A/B timing inside one
+ * process; results are identical either way).  bit0: tile kernel walks tiles row-major instead of heaviest-first. */
+enum SvrOption { SVR_OPT_COUNT_FRAGMENTS = 1, SVR_OPT_KERNEL_TIMING = 2, SVR_OPT_TILE_CYCLES = 3, SVR_OPT_TUNING = 4 };
 int svr_set_option(SvrContext* ctx, int option, int64_t value);
 
 /* Parity test hook: ask the next instrumented pass (SVR_OPT_COUNT_FRAGMENTS = 1) to record the
@@ -230,7 +234,7 @@ int svr_debug_read_trace(SvrContext* ctx, float out[64]);
  * counts may be NULL to query it, else must hold 2 * n_tiles entries.  HIP library only. */
 int svr_debug_read_bins(SvrContext* ctx, uint32_t* counts, size_t capacity, uint32_t* n_tiles);
 /* Profiling hook: shader-clock cycles each tile's workgroup spent in its four phases (visibility,
- * shading, transparent layers, write-back) during the last instrumented pass: 4 * n_tiles entries.
+ * shading, transparent layers, write-back) during the last pass run with SVR_OPT_TILE_CYCLES: 4 * n_tiles entries.
  * HIP library only. */
 int svr_debug_read_tile_cycles(SvrContext* ctx, uint32_t* cycles, size_t capacity);
 

@@ -67,6 +67,8 @@ MIPMAP_NEAREST, MIPMAP_LINEAR = 0, 1
 LOD_CLAMP_NONE = 1000.0
 OPT_COUNT_FRAGMENTS = 1
 OPT_KERNEL_TIMING = 2
+OPT_TILE_CYCLES = 3
+OPT_TUNING = 4
 
 # every symbol include/svr.h declares
 SYMBOLS = ["svr_create", "svr_destroy", "svr_set_stream", "svr_bind_targets", "svr_get_targets",

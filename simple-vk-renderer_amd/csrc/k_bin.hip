@@ -21,9 +21,9 @@ struct EdgeSet {
 };
 
 __device__ __forceinline__ EdgeSet load_edges(const TriRec* rec) {
+  EdgeSet e;
   const double2* p = reinterpret_cast<const double2*>(rec);
   double2 a = p[2], b = p[3], c = p[4], d = p[5];
-  EdgeSet e;
   e.A0 = a.x; e.A1 = a.y; e.A2 = b.x; e.B0 = b.y; e.B1 = c.x; e.B2 = c.y; e.C0 = d.x; e.C1 = d.y;
   e.C2 = rec->C[2];
   return e;
@@ -74,23 +74,54 @@ __global__ __launch_bounds__(256) void bin_kernel(FrameParams P) {
   int nt = valid ? ntx * nty : 0;
   uint32_t binbase = (flags & F_TRANSPARENT) ? P.n_tiles : 0u;
 
-  if (valid && nt <= SMALL_MAX_TILES) {
-    if (nt <= 4) {
-      for (int ty = ty0; ty <= ty1; ty++)
-        for (int tx = tx0; tx <= tx1; tx++) emit<FILL>(P, binbase + (uint32_t)ty * P.tiles_x + (uint32_t)tx, r);
+  // Small triangles (<= 16 tiles): step j emits every lane's j-th tile.  Neighbouring triangles of a
+  // mesh land in the same few tiles, so the lanes of a wave that target the same bin are merged into
+  // ONE atomic (device-scope atomics run at the memory side and serialise per line: unmerged, the
+  // 16 counters of a 64-byte line made this kernel atomic-bound).
+  uint32_t lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  bool small = valid && nt <= SMALL_MAX_TILES;
+  EdgeSet e;
+  if (small && nt > 4) e = load_edges(P.recs + r);
+  for (int j = 0; __ballot(small && j < nt); j++) {
+    bool has = small && j < nt;
+    uint32_t bin = 0;
+    if (has) {
+      int ty = ty0 + j / ntx, tx = tx0 + j % ntx;
+      if (nt > 4) {
+        int x0 = max(minx, (int)P.sx + tx * TILE), x1 = min(maxx, (int)P.sx + tx * TILE + TILE - 1);
+        int y0 = max(miny, (int)P.sy + ty * TILE), y1 = min(maxy, (int)P.sy + ty * TILE + TILE - 1);
+        has = box_overlaps(e, x0, y0, x1, y1);
+      }
+      bin = binbase + (uint32_t)ty * P.tiles_x + (uint32_t)tx;
+    }
+    unsigned long long todo = __ballot(has);
+    uint32_t leader = lane, rank = 0, cnt = 0;
+    while (todo) {
+      int l = __ffsll((long long)todo) - 1;
+      uint32_t b = __shfl(bin, l);
+      unsigned long long same = __ballot(has && bin == b);
+      if (has && bin == b) {
+        leader = (uint32_t)l;
+        rank = (uint32_t)__popcll(same & below);
+        cnt = (uint32_t)__popcll(same);
+      }
+      todo &= ~same;
+    }
+    if (!FILL) {
+      if (has && leader == lane) atomicAdd(&P.tile_count[bin], cnt);
     } else {
-      EdgeSet e = load_edges(P.recs + r);
-      for (int ty = ty0; ty <= ty1; ty++)
-        for (int tx = tx0; tx <= tx1; tx++) {
-          int x0 = max(minx, (int)P.sx + tx * TILE), x1 = min(maxx, (int)P.sx + tx * TILE + TILE - 1);
-          int y0 = max(miny, (int)P.sy + ty * TILE), y1 = min(maxy, (int)P.sy + ty * TILE + TILE - 1);
-          if (box_overlaps(e, x0, y0, x1, y1)) emit<FILL>(P, binbase + (uint32_t)ty * P.tiles_x + (uint32_t)tx, r);
-        }
+      uint32_t base = 0;
+      if (has && leader == lane) base = atomicAdd(&P.tile_cursor[bin], cnt);
+      base = __shfl(base, (int)leader);
+      if (has) {
+        uint32_t pos = P.tile_offset[bin] + base + rank;
+        if (pos < P.bin_cap) P.bins[pos] = r;
+      }
     }
   }
   // large triangles: the wave takes them one at a time, 64 tiles per step
   unsigned long long big = __ballot(valid && nt > SMALL_MAX_TILES);
-  uint32_t lane = threadIdx.x & 63;
   while (big) {
     int src = __ffsll((long long)big) - 1;
     big &= big - 1;
@@ -110,27 +141,33 @@ __global__ __launch_bounds__(256) void bin_kernel(FrameParams P) {
 
 // exclusive scan of tile_count[0 .. 2*n_tiles) by one 1024-thread workgroup
 __global__ __launch_bounds__(1024) void scan_kernel(FrameParams P) {
-  __shared__ uint32_t part[1024];
+  __shared__ uint32_t wave_tot[16];
   uint32_t n = 2u * P.n_tiles;
   uint32_t per = (n + 1023u) / 1024u;
   uint32_t b = threadIdx.x * per, e = min(b + per, n);
+  uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   uint32_t sum = 0;
   for (uint32_t i = b; i < e; i++) sum += P.tile_count[i];
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {
-    uint32_t v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0u;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
+  // inclusive scan inside the wave by shuffles, then over the 16 wave totals
+  uint32_t inc = sum;
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t v = __shfl_up(inc, off);
+    if ((int)lane >= off) inc += v;
   }
-  uint32_t run = part[threadIdx.x] - sum;
+  if (lane == 63) wave_tot[wv] = inc;
+  __syncthreads();
+  uint32_t wave_base = 0, total = 0;
+  for (uint32_t w = 0; w < 16; w++) {
+    uint32_t t = wave_tot[w];
+    if (w < wv) wave_base += t;
+    total += t;
+  }
+  uint32_t run = wave_base + inc - sum;
   for (uint32_t i = b; i < e; i++) {
     P.tile_offset[i] = run;
     run += P.tile_count[i];
   }
-  if (threadIdx.x == 1023) {
-    uint32_t total = part[1023];
+  if (threadIdx.x == 0) {
     P.counters->total_entries = total;
     if (total > P.bin_cap) atomicOr(&P.counters->overflow, 4u);
   }

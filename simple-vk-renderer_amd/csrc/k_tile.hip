@@ -30,26 +30,23 @@ namespace svr {
 constexpr int BATCH = 64;  // triangles staged per LDS batch == wave size: 64 x 128 B = 8 KiB
 
 struct CovTri {  // the coverage half as read back from LDS (wave-uniform values)
-  int minx, miny, maxx, maxy;
+  int minx, miny;
   uint32_t key, flags;
   float z0, dz1, dz2, inv_area;
-  double A0, A1, A2, B0, B1, B2, C0, C1, C2;
+  uint4 w0, w1, w2, w3, w4;  // bytes 32..111: the nine fp64 edge coefficients, decoded where used
 };
+__device__ __forceinline__ double dbl(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 
 __device__ __forceinline__ CovTri read_cov(const uint4* s) {
   CovTri t;
   uint4 h = s[0];
   t.minx = (int)(int16_t)(h.x & 0xffffu);
   t.miny = (int)(int16_t)(h.x >> 16);
-  t.maxx = (int)(int16_t)(h.y & 0xffffu);
-  t.maxy = (int)(int16_t)(h.y >> 16);
   t.key = h.z;
   t.flags = h.w;
   float4 z = reinterpret_cast<const float4*>(s)[1];
   t.z0 = z.x; t.dz1 = z.y; t.dz2 = z.z; t.inv_area = z.w;
-  const double2* d = reinterpret_cast<const double2*>(s);
-  double2 a = d[2], b = d[3], c = d[4], e = d[5], f = d[6];
-  t.A0 = a.x; t.A1 = a.y; t.A2 = b.x; t.B0 = b.y; t.B1 = c.x; t.B2 = c.y; t.C0 = e.x; t.C1 = e.y; t.C2 = f.x;
+  t.w0 = s[2]; t.w1 = s[3]; t.w2 = s[4]; t.w3 = s[5]; t.w4 = s[6];
   return t;
 }
 
@@ -137,8 +134,12 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
   // s5 = da2[1..4] | s6 = da2[5..7],pad
   uint32_t flags = hdr.w;
   float inv_area = zrow.w;
-  double A1 = c2.y, B1 = c4.x, C1 = c5.y;
-  double A2 = c3.x, B2 = c4.y, C2 = c6.x;
+  double A1, B1, A2, B2, e1, e2;
+  double C1 = c5.y, C2 = c6.x;
+  A1 = c2.y; B1 = c4.x; A2 = c3.x; B2 = c4.y;
+  double dx = (double)px, dy = (double)py;
+  e1 = fma(A1, dx, fma(B1, dy, C1)) + ((flags & F_T1) ? 1.0 : 0.0);
+  e2 = fma(A2, dx, fma(B2, dy, C2)) + ((flags & F_T2) ? 1.0 : 0.0);
   TexD t;
   t.base = reinterpret_cast<const uint8_t*>(__double_as_longlong(c6.y));
   t.w = td.x & 0xffffu;
@@ -149,10 +150,7 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
   t.filters = td.y >> 24;
   t.min_lod = u2f(td.z);
   t.max_lod = u2f(td.w);
-  // unbiased edge values at the pixel and at its horizontal / vertical quad partners
-  double dx = (double)px, dy = (double)py;
-  double e1 = fma(A1, dx, fma(B1, dy, C1)) + ((flags & F_T1) ? 1.0 : 0.0);
-  double e2 = fma(A2, dx, fma(B2, dy, C2)) + ((flags & F_T2) ? 1.0 : 0.0);
+  // e1,e2: unbiased edge values at the pixel; its horizontal / vertical quad partners are +-A, +-B away
   float b1 = (float)e1 * inv_area, b2 = (float)e2 * inv_area;
   float q0 = s0.x, dq1 = s0.y, dq2 = s0.z;
   float r = 1.0f / fmaf(b2, dq2, fmaf(b1, dq1, q0));
@@ -276,47 +274,71 @@ struct Codec<SVR_COLOR_RGBA8> {
 };
 
 // ------------------------------------------------------------------------------------------------
-// One triangle against the wave's four 8x8 blocks.
+// per-pixel depth test + bookkeeping shared by both coverage paths
+template <bool PEEL>
+__device__ __forceinline__ void resolve(bool inside, float b1, float b2, const CovTri& t, uint32_t ri, uint32_t& zbit,
+                                        uint32_t& key, uint32_t& rec, uint32_t last) {
+  float z = fmaf(b2, t.dz2, fmaf(b1, t.dz1, t.z0));
+  z = fminf(fmaxf(z, 0.0f), 1.0f) + 0.0f;
+  uint32_t zb = f2u(z);
+  if (!PEEL) {
+    bool better = inside && (zb > zbit || (zb == zbit && t.key > key));
+    if (better) {
+      zbit = zb;
+      key = t.key;
+      rec = ri;
+    }
+  } else {
+    bool take = inside && zb >= zbit && t.key > last && t.key < key;
+    if (take) {
+      key = t.key;
+      rec = ri;
+    }
+  }
+}
+
+// One triangle against the blocks of the wave's quadrant selected by bm (an SGPR).
 //   PEEL == false: keep the fragment with the largest (depth, key)            (opaque visibility)
 //   PEEL == true : keep the depth-passing fragment with the smallest key > last   (next layer)
 template <bool PEEL, bool INSTR>
-__device__ __forceinline__ void raster_triangle(const CovTri& t, uint32_t ri, int ox, int oy, double dpx, double dpy,
+__device__ __forceinline__ void raster_triangle(const CovTri& t, uint32_t ri, uint32_t bm, int ipx, int ipy,
                                                 const bool (&pix_ok)[4], uint32_t (&zbits)[4], uint32_t (&keys)[4],
                                                 uint32_t (&recs)[4], const uint32_t (&last)[4], bool count_now,
                                                 uint32_t& n_raster) {
-  double e0 = fma(t.A0, dpx, fma(t.B0, dpy, t.C0));
-  double e1 = fma(t.A1, dpx, fma(t.B1, dpy, t.C1));
-  double e2 = fma(t.A2, dpx, fma(t.B2, dpy, t.C2));
-  double u1 = (t.flags & F_T1) ? 1.0 : 0.0, u2 = (t.flags & F_T2) ? 1.0 : 0.0;
+  int u1i = (t.flags & F_T1) ? 1 : 0, u2i = (t.flags & F_T2) ? 1 : 0;
+  double A0 = dbl(t.w0.x, t.w0.y), A1 = dbl(t.w0.z, t.w0.w), A2 = dbl(t.w1.x, t.w1.y), B0 = dbl(t.w1.z, t.w1.w);
+  double B1 = dbl(t.w2.x, t.w2.y), B2 = dbl(t.w2.z, t.w2.w), C0 = dbl(t.w3.x, t.w3.y), C1 = dbl(t.w3.z, t.w3.w);
+  double C2 = dbl(t.w4.x, t.w4.y);
+  double dpx = (double)ipx, dpy = (double)ipy;
+  double e0 = fma(A0, dpx, fma(B0, dpy, C0));
+  double e1 = fma(A1, dpx, fma(B1, dpy, C1));
+  double e2 = fma(A2, dpx, fma(B2, dpy, C2));
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    int bx = ox + (k & 1) * 8, by = oy + (k >> 1) * 8;
-    if (t.maxx < bx || t.minx > bx + 7 || t.maxy < by || t.miny > by + 7) continue;  // wave-uniform
+    if (!(bm & (1u << k))) continue;  // bm is an SGPR (readlane): a real scalar branch, the block is skipped
     double kx = (double)((k & 1) * 8), ky = (double)((k >> 1) * 8);
-    double f0 = fma(t.A0, kx, fma(t.B0, ky, e0));
-    double f1 = fma(t.A1, kx, fma(t.B1, ky, e1));
-    double f2 = fma(t.A2, kx, fma(t.B2, ky, e2));
+    double f0 = fma(A0, kx, fma(B0, ky, e0));
+    double f1 = fma(A1, kx, fma(B1, ky, e1));
+    double f2 = fma(A2, kx, fma(B2, ky, e2));
     bool inside = pix_ok[k] && f0 >= 0.0 && f1 >= 0.0 && f2 >= 0.0;
     if (INSTR && count_now) n_raster += inside ? 1u : 0u;
-    float b1 = (float)(f1 + u1) * t.inv_area, b2 = (float)(f2 + u2) * t.inv_area;
-    float z = fmaf(b2, t.dz2, fmaf(b1, t.dz1, t.z0));
-    z = fminf(fmaxf(z, 0.0f), 1.0f) + 0.0f;
-    uint32_t zb = f2u(z);
-    if (!PEEL) {
-      bool better = inside && (zb > zbits[k] || (zb == zbits[k] && t.key > keys[k]));
-      if (better) {
-        zbits[k] = zb;
-        keys[k] = t.key;
-        recs[k] = ri;
-      }
-    } else {
-      bool take = inside && zb >= zbits[k] && t.key > last[k] && t.key < keys[k];
-      if (take) {
-        keys[k] = t.key;
-        recs[k] = ri;
-      }
-    }
+    float b1 = (float)(f1 + (double)u1i) * t.inv_area, b2 = (float)(f2 + (double)u2i) * t.inv_area;
+    resolve<PEEL>(inside, b1, b2, t, ri, zbits[k], keys[k], recs[k], last[k]);
   }
+}
+
+// Lane i classifies triangle i of the staged batch against the wave's quadrant: bit k of the result
+// is set when the triangle's bbox touches 8x8 block k (0 = the wave can skip the triangle).
+__device__ __forceinline__ uint32_t classify(const uint4* s_cov, uint32_t lane, uint32_t cnt, int ox, int oy) {
+  if (lane >= cnt) return 0u;
+  uint4 h = s_cov[lane * 8u];
+  int minx = (int)(int16_t)(h.x & 0xffffu), miny = (int)(int16_t)(h.x >> 16);
+  int maxx = (int)(int16_t)(h.y & 0xffffu), maxy = (int)(int16_t)(h.y >> 16);
+  uint32_t cx = (maxx >= ox && minx <= ox + 7 ? 1u : 0u) | (maxx >= ox + 8 && minx <= ox + 15 ? 2u : 0u);
+  uint32_t cy = (maxy >= oy && miny <= oy + 7 ? 1u : 0u) | (maxy >= oy + 8 && miny <= oy + 15 ? 2u : 0u);
+  // block k = (k&1: column, k>>1: row)
+  return ((cx & 1u) && (cy & 1u) ? 1u : 0u) | ((cx & 2u) && (cy & 1u) ? 2u : 0u) |
+         ((cx & 1u) && (cy & 2u) ? 4u : 0u) | ((cx & 2u) && (cy & 2u) ? 8u : 0u);
 }
 
 // Walk one bin (staged through LDS) and update the per-pixel state.
@@ -325,7 +347,6 @@ __device__ __forceinline__ void walk_bin(const FrameParams& P, uint4* s_cov, uin
                                          uint32_t n, int ox, int oy, int lx, int ly, const bool (&pix_ok)[4],
                                          uint32_t (&zbits)[4], uint32_t (&keys)[4], uint32_t (&recs)[4],
                                          const uint32_t (&last)[4], bool count_now, uint32_t& n_raster) {
-  const double dpx = (double)(ox + lx), dpy = (double)(oy + ly);
   const uint32_t lane = threadIdx.x & 63u;
   for (uint32_t b0 = 0; b0 < n; b0 += BATCH) {
     uint32_t cnt = min((uint32_t)BATCH, n - b0);
@@ -337,14 +358,8 @@ __device__ __forceinline__ void walk_bin(const FrameParams& P, uint4* s_cov, uin
     }
     __syncthreads();
     // classify the whole batch at once: lane i looks at triangle i's bbox only
-    bool hit = false;
-    if (lane < cnt) {
-      uint4 h = s_cov[lane * 8u];
-      int hminx = (int)(int16_t)(h.x & 0xffffu), hminy = (int)(int16_t)(h.x >> 16);
-      int hmaxx = (int)(int16_t)(h.y & 0xffffu), hmaxy = (int)(int16_t)(h.y >> 16);
-      hit = !(hmaxx < ox || hminx > ox + 15 || hmaxy < oy || hminy > oy + 15);
-    }
-    unsigned long long todo = __ballot(hit);
+    uint32_t my_bm = classify(s_cov, lane, cnt, ox, oy);
+    unsigned long long todo = __ballot(my_bm != 0u);
     if (!todo) continue;
     // accepted triangles only, the next one's LDS reads in flight while this one is rasterised
     int i = __ffsll((long long)todo) - 1;
@@ -357,7 +372,8 @@ __device__ __forceinline__ void walk_bin(const FrameParams& P, uint4* s_cov, uin
       todo &= todo - 1;
       CovTri nxt = read_cov(s_cov + (uint32_t)ni * 8u);
       uint32_t nri = s_idx[ni];
-      raster_triangle<PEEL, INSTR>(cur, cri, ox, oy, dpx, dpy, pix_ok, zbits, keys, recs, last, count_now, n_raster);
+      uint32_t bm = (uint32_t)__builtin_amdgcn_readlane((int)my_bm, i);
+      raster_triangle<PEEL, INSTR>(cur, cri, bm, ox + lx, oy + ly, pix_ok, zbits, keys, recs, last, count_now, n_raster);
       if (!more) break;
       cur = nxt;
       cri = nri;
@@ -424,9 +440,8 @@ __device__ __forceinline__ void flush_fragments(const FrameParams& P, typename C
 template <int FMT, bool INSTR>
 __device__ __forceinline__ void walk_ordered(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, uint32_t bin_base,
                                              uint32_t n, int ox, int oy, int lx, int ly, const bool (&pix_ok)[4],
-                                             const uint32_t (&zbits)[4], typename Codec<FMT>::enc_t* col, uint2* q,
+                                             uint32_t (&zbits)[4], typename Codec<FMT>::enc_t* col, uint2* q,
                                              uint32_t* slot, uint32_t& n_raster, uint32_t& n_shaded) {
-  const double dpx = (double)(ox + lx), dpy = (double)(oy + ly);
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long below = (1ull << lane) - 1ull;
   uint32_t qn = 0;
@@ -439,37 +454,24 @@ __device__ __forceinline__ void walk_ordered(const FrameParams& P, uint4* s_cov,
       if ((piece & 7u) == 0) s_idx[piece >> 3] = ri;
     }
     __syncthreads();
-    bool hit = false;
-    if (lane < cnt) {
-      uint4 h = s_cov[lane * 8u];
-      int hminx = (int)(int16_t)(h.x & 0xffffu), hminy = (int)(int16_t)(h.x >> 16);
-      int hmaxx = (int)(int16_t)(h.y & 0xffffu), hmaxy = (int)(int16_t)(h.y >> 16);
-      hit = !(hmaxx < ox || hminx > ox + 15 || hmaxy < oy || hminy > oy + 15);
-    }
-    unsigned long long todo = __ballot(hit);
+    uint32_t my_bm = classify(s_cov, lane, cnt, ox, oy);
+    unsigned long long todo = __ballot(my_bm != 0u);
     while (todo) {  // ascending bit order == submission order inside the sorted batch
       int i = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
+      uint32_t bm = (uint32_t)__builtin_amdgcn_readlane((int)my_bm, i);
       CovTri t = read_cov(s_cov + (uint32_t)i * 8u);
       uint32_t ri = s_idx[i];
-      double e0 = fma(t.A0, dpx, fma(t.B0, dpy, t.C0));
-      double e1 = fma(t.A1, dpx, fma(t.B1, dpy, t.C1));
-      double e2 = fma(t.A2, dpx, fma(t.B2, dpy, t.C2));
-      double u1 = (t.flags & F_T1) ? 1.0 : 0.0, u2 = (t.flags & F_T2) ? 1.0 : 0.0;
+      // depth-passing pixels of this triangle, via the peel form of the shared coverage code:
+      // with key bounds (0, ~0) it marks exactly the pixels that are covered and pass GREATER_OR_EQUAL
+      uint32_t ck[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      uint32_t cr[4] = {NO_REC, NO_REC, NO_REC, NO_REC};
+      const uint32_t none[4] = {0u, 0u, 0u, 0u};
+      raster_triangle<true, INSTR>(t, ri, bm, ox + lx, oy + ly, pix_ok, zbits, ck, cr, none, true, n_raster);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        int bx = ox + (k & 1) * 8, by = oy + (k >> 1) * 8;
-        if (t.maxx < bx || t.minx > bx + 7 || t.maxy < by || t.miny > by + 7) continue;  // wave-uniform
-        double kx = (double)((k & 1) * 8), ky = (double)((k >> 1) * 8);
-        double f0 = fma(t.A0, kx, fma(t.B0, ky, e0));
-        double f1 = fma(t.A1, kx, fma(t.B1, ky, e1));
-        double f2 = fma(t.A2, kx, fma(t.B2, ky, e2));
-        bool inside = pix_ok[k] && f0 >= 0.0 && f1 >= 0.0 && f2 >= 0.0;
-        if (INSTR) n_raster += inside ? 1u : 0u;
-        float b1 = (float)(f1 + u1) * t.inv_area, b2 = (float)(f2 + u2) * t.inv_area;
-        float z = fmaf(b2, t.dz2, fmaf(b1, t.dz1, t.z0));
-        z = fminf(fmaxf(z, 0.0f), 1.0f) + 0.0f;
-        bool pass = inside && f2u(z) >= zbits[k];  // depth test GREATER_OR_EQUAL, no depth write
+        if (!(bm & (1u << k))) continue;  // scalar branch
+        bool pass = cr[k] != NO_REC;
         unsigned long long m = __ballot(pass);
         if (m) {
           if (pass) q[qn + (uint32_t)__popcll(m & below)] = make_uint2((uint32_t)k * 64u + lane, ri);
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
   // Workgroups are dispatched in blockIdx order: walk the tiles heaviest class first (scan_kernel's
   // tile_order).  Tiles are dealt round-robin over the 8 XCDs; a contiguous span per XCD was tried
   // and loses: the heavy rows of the frame all land on one XCD and the other seven idle.
-  uint32_t tile = P.tile_order[blockIdx.x];
+  uint32_t tile = (P.tuning & TUNE_NO_TILE_ORDER) ? blockIdx.x : P.tile_order[blockIdx.x];
   uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
   uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   int ox = (int)(P.sx + tx * TILE + (wave & 1u) * 16u), oy = (int)(P.sy + ty * TILE + (wave >> 1) * 16u);
@@ -548,14 +550,15 @@ __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
     zero4[k] = 0u;
   }
   uint32_t n_raster = 0, n_shaded = 0;
-  long long stamp[5] = {0, 0, 0, 0, 0};  // instrumented variant only: shader-clock stamps per phase
-  if (INSTR) stamp[0] = clock64();
+  long long stamp[5] = {0, 0, 0, 0, 0};  // SVR_OPT_TILE_CYCLES: shader-clock stamps per phase
+  const bool stamps = P.tile_cycles != nullptr;
+  if (stamps) stamp[0] = clock64();
 
   // ---- phase A: opaque visibility
   uint32_t n_op = P.tile_count[tile], n_tr = P.tile_count[P.n_tiles + tile];
   if (n_op) walk_bin<false, INSTR>(P, s_cov, s_idx, P.tile_offset[tile], n_op, ox, oy, lx, ly, pix_ok, zbits, keys, recs, zero4, true, n_raster);
 
-  if (INSTR) stamp[1] = clock64();
+  if (stamps) stamp[1] = clock64();
   // ---- phase B: shade visible pixels once
   enc_t enc[4];
   bool dirty[4];
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
     }
   }
 
-  if (INSTR) stamp[2] = clock64();
+  if (stamps) stamp[2] = clock64();
   // ---- phase C: transparent fragments in submission order
   if (n_tr && n_tr <= SORT_CAP) {
     uint32_t tbase = P.tile_offset[P.n_tiles + tile];
@@ -636,7 +639,7 @@ __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
     }
   }
 
-  if (INSTR) stamp[3] = clock64();
+  if (stamps) stamp[3] = clock64();
   // ---- phase D: write back
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -646,11 +649,12 @@ __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
     P.depth[p] = u2f(zbits[k]);
     if (dirty[k]) reinterpret_cast<enc_t*>(P.color)[p] = enc[k];
   }
-  if (INSTR) {
+  if (stamps) {
     stamp[4] = clock64();
-    if (P.tile_cycles && threadIdx.x == 0) {
+    if (threadIdx.x == 0)
       for (int k = 0; k < 4; k++) P.tile_cycles[tile * 4u + k] = (uint32_t)(stamp[k + 1] - stamp[k]);
-    }
+  }
+  if (INSTR) {
     for (int off = 32; off > 0; off >>= 1) {
       n_raster += __shfl_down(n_raster, off);
       n_shaded += __shfl_down(n_shaded, off);

@@ -116,7 +116,7 @@ struct SvrContext {
   size_t tex_slots = 0;
 
   // per-pass device buffers
-  DevBuf d_draws, d_chunks, d_recs, d_clipq, d_tiles, d_bins, d_counters, d_cvt;
+  DevBuf d_draws, d_chunks, d_recs, d_clipq, d_tiles, d_bins, d_cvt;
   uint32_t clip_cap = 0, extra_cap = 0, bin_cap = 0;
   // pinned host staging (ring) + readback
   static const int RING = 3;
@@ -139,6 +139,8 @@ struct SvrContext {
   bool pending = false;      // a pass has been enqueued and not validated yet
   FrameParams last{};        // parameters of that pass, for replay
   bool instrument = false;
+  bool tile_cycles = false;
+  uint32_t tuning = 0;
   int trace_x = -1, trace_y = -1;
   DevBuf d_trace, d_tile_cycles;
   SvrStats stats{};
@@ -275,9 +277,9 @@ int enqueue_pass(SvrContext* ctx, const FrameParams& P) {
     for (int k = 0; k < 4; k++)
       if (!ctx->tev[ts][k]) HIPCHK(hipEventCreate(&ctx->tev[ts][k]));
   }
-  HIPCHK(hipMemsetAsync(P.counters, 0, sizeof(Counters), s));
-  // tile_count and tile_cursor are adjacent: one memset
-  HIPCHK(hipMemsetAsync(P.tile_count, 0, (size_t)P.n_tiles * 4 * sizeof(uint32_t), s));
+  // counters, tile_count and tile_cursor are adjacent in one allocation: one memset node
+  static_assert(sizeof(Counters) == 64, "Counters is the 64-byte head of the tile buffer");
+  HIPCHK(hipMemsetAsync(P.counters, 0, sizeof(Counters) + (size_t)P.n_tiles * 4 * sizeof(uint32_t), s));
   HIPCHK(hipEventRecord(ctx->ev_start, s));
   if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][0], s));
   launch_setup(P, s);
@@ -304,20 +306,19 @@ int enqueue_pass(SvrContext* ctx, const FrameParams& P) {
 int bind_pass_buffers(SvrContext* ctx, FrameParams& P) {
   if (int e = ctx->d_recs.ensure(((size_t)P.n_tris + ctx->extra_cap) * sizeof(TriRec))) return e;
   if (int e = ctx->d_clipq.ensure((size_t)ctx->clip_cap * sizeof(ClipItem))) return e;
-  if (int e = ctx->d_tiles.ensure((size_t)P.n_tiles * 7 * sizeof(uint32_t))) return e;
+  if (int e = ctx->d_tiles.ensure(sizeof(Counters) + (size_t)P.n_tiles * 7 * sizeof(uint32_t))) return e;
   if (int e = ctx->d_bins.ensure((size_t)ctx->bin_cap * sizeof(uint32_t))) return e;
-  if (int e = ctx->d_counters.ensure(sizeof(Counters))) return e;
   P.recs = (TriRec*)ctx->d_recs.p;
   P.extra_cap = ctx->extra_cap;
   P.clip_queue = (ClipItem*)ctx->d_clipq.p;
   P.clip_cap = ctx->clip_cap;
-  P.tile_count = (uint32_t*)ctx->d_tiles.p;
+  P.counters = (Counters*)ctx->d_tiles.p;
+  P.tile_count = (uint32_t*)((char*)ctx->d_tiles.p + sizeof(Counters));
   P.tile_cursor = P.tile_count + (size_t)P.n_tiles * 2;
   P.tile_offset = P.tile_count + (size_t)P.n_tiles * 4;
   P.tile_order = P.tile_count + (size_t)P.n_tiles * 6;
   P.bins = (uint32_t*)ctx->d_bins.p;
   P.bin_cap = ctx->bin_cap;
-  P.counters = (Counters*)ctx->d_counters.p;
   return SVR_OK;
 }
 
@@ -389,8 +390,9 @@ int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& 
   P.trace_x = ctx->trace_x;
   P.trace_y = ctx->trace_y;
   P.trace_buf = (ctx->instrument && ctx->trace_x >= 0) ? (float*)ctx->d_trace.p : nullptr;
+  P.tuning = ctx->tuning;
   P.tile_cycles = nullptr;
-  if (ctx->instrument) {
+  if (ctx->tile_cycles) {
     if (int e = ctx->d_tile_cycles.ensure((size_t)P.n_tiles * 16)) return e;
     P.tile_cycles = (uint32_t*)ctx->d_tile_cycles.p;
   }
@@ -489,7 +491,7 @@ void svr_destroy(SvrContext* ctx) {
   for (auto& im : ctx->images)
     if (im.base) (void)hipFree(im.base);
   DevBuf* bufs[] = {&ctx->tex_table, &ctx->d_draws, &ctx->d_chunks, &ctx->d_recs, &ctx->d_clipq,
-                    &ctx->d_tiles,   &ctx->d_bins,  &ctx->d_counters, &ctx->d_cvt, &ctx->d_trace, &ctx->d_tile_cycles};
+                    &ctx->d_tiles,   &ctx->d_bins,  &ctx->d_cvt,    &ctx->d_trace, &ctx->d_tile_cycles};
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < SvrContext::RING; i++) {
     if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
@@ -883,6 +885,14 @@ int svr_set_option(SvrContext* ctx, int option, int64_t value) {
     ctx->instrument = value != 0;
     return SVR_OK;
   }
+  if (option == SVR_OPT_TUNING) {
+    ctx->tuning = (uint32_t)value;
+    return SVR_OK;
+  }
+  if (option == SVR_OPT_TILE_CYCLES) {
+    ctx->tile_cycles = value != 0;
+    return SVR_OK;
+  }
   if (option == SVR_OPT_KERNEL_TIMING) {
     if (int e = use_device(ctx)) return e;
     for (int i = 0; i < SvrContext::TRING; i++)
@@ -936,7 +946,7 @@ int svr_debug_read_tile_cycles(SvrContext* ctx, uint32_t* cycles, size_t capacit
   if (int e = use_device(ctx)) return e;
   if (int e = finish_pending(ctx)) return e;
   if (!ctx->last.tile_cycles || capacity < 4 * (size_t)ctx->last.n_tiles)
-    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_debug_read_tile_cycles: last pass was not instrumented or buffer too small");
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_debug_read_tile_cycles: SVR_OPT_TILE_CYCLES was off for the last pass or buffer too small");
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(cycles, ctx->last.tile_cycles, 16 * (size_t)ctx->last.n_tiles, hipMemcpyDeviceToHost));
   return SVR_OK;

@@ -23,6 +23,9 @@ constexpr uint32_t F_T2 = 2u;            // edge 2 is not top-left
 constexpr uint32_t F_KIND_SHIFT = 4;     // 2 bits
 constexpr uint32_t F_TRANSPARENT = 256u;
 
+// SVR_OPT_TUNING bits: switch an optimisation off at run time so it can be A/B-timed in one process
+constexpr uint32_t TUNE_NO_TILE_ORDER = 1u;   // tile kernel walks tiles row-major instead of heaviest-first
+
 // One draw call (RenderObject after cull+sort), 128 bytes.
 struct DrawDesc {
   float mat[16];            // MESH: world matrix (push constant); TEX_IMAGE: render_matrix
@@ -69,7 +72,9 @@ __host__ __device__ inline uint32_t mip_offset(uint32_t lw, uint32_t lh, uint32_
 // A set-up triangle, 256 bytes: first half is all the coverage/depth loop reads, second half only
 // the winners' shading reads.  Edge functions are evaluated at integer pixel indices (px,py):
 // e_i = A[i]*px + B[i]*py + C[i]  (C already carries the top-left bias); everything is an exact
-// integer < 2^53 held in a double.
+// integer < 2^53 held in a double.  (An int32 form for triangles under 64 px, evaluated with
+// v_mad_i32_i24, was measured 7 % SLOWER in the tile kernel: at its occupancy a lone wave issues one
+// VALU instruction per ~4 cycles, which is also the cost of a 16-lane/clk v_fma_f64.)
 struct TriRec {
   int16_t minx, miny, maxx, maxy;  // inclusive pixel bbox clamped to the scissor; minx>maxx = invalid
   uint32_t key;                    // submission sequence number + 1
@@ -102,7 +107,7 @@ struct Counters {
   unsigned long long rasterized;
   unsigned long long shaded;
   unsigned long long binned;
-  unsigned long long pad;
+  unsigned long long pad[3];  // 64 bytes: the counters head the tile-counter allocation (one memset)
 };
 
 struct FrameParams {
@@ -133,7 +138,9 @@ struct FrameParams {
   uint32_t instrument;            // count fragments/triangles with device atomics (not in timed runs)
   int trace_x, trace_y;           // instrumented passes only: dump the shading of this pixel
   float* trace_buf;               // 64 floats or NULL
-  uint32_t* tile_cycles;          // instrumented passes: [n_tiles][4] shader-clock cycles of phases A..D
+  uint32_t* tile_cycles;          // SVR_OPT_TILE_CYCLES: [n_tiles][4] shader-clock cycles of phases A..D
+  uint32_t tuning;                // SVR_OPT_TUNING bits (A/B switches for benchmarking, default 0)
+  uint32_t pad_t;
   SvrSceneData scene;
 };
 
@@ -308,7 +315,6 @@ __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, cons
   h.z = key;
   h.w = flags;
   float4 zrow = make_float4(s0.zs, s1.zs - s0.zs, s2.zs - s0.zs, inv_area);
-  q[0] = h;
   reinterpret_cast<float4*>(out)[1] = zrow;
   double2* dq = reinterpret_cast<double2*>(out);
   dq[2] = make_double2(A[0], A[1]);
@@ -316,6 +322,7 @@ __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, cons
   dq[4] = make_double2(B[1], B[2]);
   dq[5] = make_double2(C[0], C[1]);
   out->C[2] = C[2];
+  q[0] = h;
   out->tex_base = tex.base;
   q[7] = make_uint4(tex.wh, tex.info, f2u(tex.min_lod), f2u(tex.max_lod));
   // shading half

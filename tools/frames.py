@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--instances", type=int, default=1)
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--hist", action="store_true")
+    ap.add_argument("--ab", default="", help="comma list of SVR_OPT_TUNING masks to time interleaved, e.g. 0,1")
     args = ap.parse_args()
     pkg = g.load_package()
     hip = pkg.load_product_library()
@@ -52,6 +53,29 @@ def main():
     print(f"{args.width}x{args.height} x{args.instances}: {dt * 1e3:.3f} ms/frame wall; geometry {st.geometry_ms:.3f} "
           f"binning {st.binning_ms:.3f} tile {st.tile_ms:.3f} ms; host record {st.mesh_draw_time:.3f} ms; "
           f"bin entries {st.bin_entries}")
+    if args.ab:
+        masks = [int(m) for m in args.ab.split(",")]
+        res = {m: [] for m in masks}
+        for rnd in range(8):
+            for m in masks:
+                r.set_option(A.OPT_TUNING, m)
+                r.set_option(A.OPT_KERNEL_TIMING, 1)
+                for _ in range(10):
+                    r.clear_color((1, 1, 1, 1))
+                    r.draw_geometry(scene, opaque, transparent)
+                r.sync()
+                s2 = r.get_stats()
+                res[m].append((s2.geometry_ms, s2.binning_ms, s2.tile_ms))
+        for m in masks:
+            a = np.array(res[m])
+            print(f"  tuning {m}: geometry/binning/tile median {np.median(a, axis=0).round(4).tolist()} min {a.min(axis=0).round(4).tolist()} ms")
+        r.set_option(A.OPT_TUNING, 0)
+    host = []
+    for _ in range(10):  # GPU idle at every call: mesh_draw_time is then pure host record cost
+        r.clear_color((1, 1, 1, 1))
+        host.append(r.draw_geometry(scene, opaque, transparent).mesh_draw_time)
+        r.sync()
+    print(f"  host record time with an idle GPU: median {float(np.median(host)):.3f} ms")
     if args.hist:
         op, tr = r.read_bins()
         for name, c in (("opaque", op), ("transparent", tr)):
@@ -61,14 +85,14 @@ def main():
         tx = (args.width + 31) // 32
         rows = op.reshape(-1, tx).sum(axis=1)
         print("  opaque entries per tile row:", rows.tolist())
-        # one instrumented frame: shader-clock cycles per tile and phase
-        r.set_option(A.OPT_COUNT_FRAGMENTS, 1)
+        # one frame of the production kernel with phase stamps: shader-clock cycles per tile and phase
+        r.set_option(A.OPT_TILE_CYCLES, 1)
         r.clear_color((1, 1, 1, 1))
         r.draw_geometry(scene, opaque, transparent)
         r.sync()
         cyc = r.read_tile_cycles().astype(np.float64)
         tot = cyc.sum(axis=1)
-        print("  tile cycles (instrumented variant): phase sums A/B/C/D (Mcycles):",
+        print("  tile cycles: phase sums A/B/C/D (Mcycles):",
               [round(float(v) / 1e6, 1) for v in cyc.sum(axis=0)])
         print("  per-tile total cycles percentiles(0,50,90,99,100):",
               np.percentile(tot, [0, 50, 90, 99, 100]).astype(int).tolist(), "sum", int(tot.sum()))
