@@ -10,7 +10,7 @@ The directory name contains a hyphen (the name the build contract asks for), so 
 """
 import os
 
-from . import abi, glmath, scenes  # noqa: F401
+from . import abi, dist, glmath, scenes  # noqa: F401
 from .abi import SvrLib, Renderer, SvrError  # noqa: F401
 
 PACKAGE_DIR = os.path.dirname(os.path.abspath(__file__))

@@ -521,7 +521,9 @@ int svr_bind_targets(SvrContext* ctx, void* color_dev, void* depth_dev) {
   if ((color_dev == nullptr) != (depth_dev == nullptr))
     return fail(SVR_ERR_INVALID_ARGUMENT, "svr_bind_targets: pass both targets or both NULL");
   if (int e = use_device(ctx)) return e;
-  if (int e = finish_pending(ctx)) return e;
+  // no fence: passes already enqueued carry their own target pointers (also for a replay), so frames
+  // can alternate between target sets while earlier ones are still in flight
+  if (int e = poll_pending(ctx)) return e;
   ctx->color = color_dev ? color_dev : ctx->color_own;
   ctx->depth = depth_dev ? (float*)depth_dev : ctx->depth_own;
   return SVR_OK;
