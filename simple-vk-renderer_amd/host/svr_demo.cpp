@@ -1,0 +1,147 @@
+// svr_demo.cpp — drives the VulkanEngine-shaped harness (svr_engine.h) for a few frames and dumps what it
+// submitted and what came back.  Used by tests/test_host_cpp.py (against the oracle on CPU, against the HIP
+// library on the GPU box) and as the smallest example of the call sequence init -> load -> draw().
+//
+//   svr_demo --lib <libsvr_*.so> --width 160 --height 90 --frames 2 --dump /tmp/prefix
+//
+// Scene: a three-level node hierarchy of cubes (exercises Node::refresh_transform's parent_matrix quirk and
+// MeshNode::Draw's world*top order) with an opaque default material and a Transparent checker one.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+#include "svr_engine.h"
+
+using namespace svrhost;
+
+static void cube(std::vector<uint32_t>& idx, std::vector<SvrVertex>& vtx) {
+  // 24 vertices / 36 indices, per-face uv in [0,1]^2, axial normals, colour 1 (same table as scenes.cube_mesh)
+  const float faces[6][3][3] = {
+      {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}},  {{0, 0, -1}, {-1, 0, 0}, {0, 1, 0}}, {{1, 0, 0}, {0, 0, -1}, {0, 1, 0}},
+      {{-1, 0, 0}, {0, 0, 1}, {0, 1, 0}}, {{0, 1, 0}, {1, 0, 0}, {0, 0, -1}},  {{0, -1, 0}, {1, 0, 0}, {0, 0, 1}}};
+  const int corner[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+  for (int f = 0; f < 6; f++) {
+    uint32_t base = (uint32_t)vtx.size();
+    for (int c = 0; c < 4; c++) {
+      SvrVertex v{};
+      for (int k = 0; k < 3; k++) {
+        v.position[k] = faces[f][0][k] * 0.5f + faces[f][1][k] * ((float)corner[c][0] - 0.5f) + faces[f][2][k] * ((float)corner[c][1] - 0.5f);
+        v.normal[k] = faces[f][0][k];
+      }
+      v.uv_x = (float)corner[c][0];
+      v.uv_y = (float)corner[c][1];
+      v.color[0] = v.color[1] = v.color[2] = v.color[3] = 1.f;
+      vtx.push_back(v);
+    }
+    const uint32_t q[6] = {0, 1, 2, 0, 2, 3};
+    for (uint32_t i : q) idx.push_back(base + i);
+  }
+}
+
+template <class T>
+static void dump(const std::string& path, const T* p, size_t n) {
+  std::ofstream f(path, std::ios::binary);
+  f.write(reinterpret_cast<const char*>(p), (std::streamsize)(n * sizeof(T)));
+}
+
+int main(int argc, char** argv) {
+  std::string lib, prefix;
+  uint32_t w = 160, h = 90;
+  int frames = 2;
+  for (int i = 1; i + 1 < argc; i += 2) {
+    std::string a = argv[i];
+    if (a == "--lib") lib = argv[i + 1];
+    else if (a == "--width") w = (uint32_t)atoi(argv[i + 1]);
+    else if (a == "--height") h = (uint32_t)atoi(argv[i + 1]);
+    else if (a == "--frames") frames = atoi(argv[i + 1]);
+    else if (a == "--dump") prefix = argv[i + 1];
+  }
+  if (lib.empty()) {
+    fprintf(stderr, "usage: svr_demo --lib <shared library exporting svr.h> [--width W --height H --frames N --dump prefix]\n");
+    return 2;
+  }
+  SvrEngine eng;
+  if (!eng.init(lib, w, h)) {
+    fprintf(stderr, "init failed: %s\n", eng.error.c_str());
+    return 1;
+  }
+  printf("backend %s, %ux%u\n", eng.api.svr_backend_name(), w, h);
+
+  // "load_gltf_meshes" by hand: one mesh with two primitives (two cubes' worth of geometry in one buffer)
+  auto mesh = std::make_shared<MeshAsset>();
+  mesh->name = "cubes";
+  std::vector<uint32_t> idx;
+  std::vector<SvrVertex> vtx;
+  const float tint[4] = {0.4f, 0.3f, 0.2f, 1.f};
+  auto transparent = eng.write_material(SVR_PASS_TRANSPARENT, tint, eng.error_checkerboard_image, eng.default_sampler_nearest);
+  auto opaque = std::make_shared<MaterialInstance>(eng.default_data);
+  for (int prim = 0; prim < 2; prim++) {
+    size_t initial_vtx = vtx.size();
+    std::vector<uint32_t> ci;
+    std::vector<SvrVertex> cv;
+    cube(ci, cv);
+    for (auto& v : cv) v.position[0] += 1.25f * (float)prim;  // second primitive sits beside the first
+    GeoSurface s;
+    s.startIndex = (uint32_t)idx.size();
+    s.count = (uint32_t)ci.size();
+    for (uint32_t i : ci) idx.push_back(i + (uint32_t)initial_vtx);  // indices rebased, src/vk_loader.cpp:311-312
+    vtx.insert(vtx.end(), cv.begin(), cv.end());
+    s.bounds = loader_bounds(vtx, initial_vtx);
+    s.material = prim == 0 ? opaque : transparent;
+    mesh->surfaces.push_back(s);
+  }
+  mesh->meshBuffers = eng.upload_mesh(idx, vtx);
+
+  auto scene = std::make_shared<LoadedScene>();
+  scene->meshes.push_back(mesh);
+  auto trs = [](svrm::vec3 t, svrm::quat q, svrm::vec3 s) {  // src/vk_loader.cpp:400-410: tm * rm * sm
+    return svrm::mul(svrm::mul(svrm::translate(svrm::identity(), t), svrm::to_mat4(q)), svrm::scale(svrm::identity(), s));
+  };
+  auto root = std::make_shared<Node>();
+  root->local_transform = trs({0, 0, -12}, {1, 0, 0, 0}, {1, 1, 1});
+  auto child = std::make_shared<MeshNode>();
+  child->mesh = mesh;
+  child->local_transform = trs({-3, 0, -9}, {0.70710677f, 0, 0.70710677f, 0}, {2, 2, 2});
+  auto grandchild = std::make_shared<MeshNode>();
+  grandchild->mesh = mesh;
+  grandchild->local_transform = trs({2, 1.5f, -7}, {1, 0, 0, 0}, {1, 1.5f, 1});
+  root->children.push_back(child);
+  child->parent = root;
+  child->children.push_back(grandchild);
+  grandchild->parent = child;
+  scene->nodes = {root, child, grandchild};
+  scene->top_nodes = {root};
+  root->refresh_transform(svrm::identity());  // src/vk_loader.cpp:430-435
+  eng.loaded_scenes["structure"] = scene;
+  eng.main_camera.position = {0, 0, 0};
+
+  for (int f = 0; f < frames; f++) {
+    eng.update_scene();
+    if (f == frames - 1 && !prefix.empty()) {
+      dump(prefix + ".scene", &eng.scene_data, 1);
+      dump(prefix + ".opaque", eng.main_draw_context.opaque_surfaces.data(), eng.main_draw_context.opaque_surfaces.size());
+      dump(prefix + ".transparent", eng.main_draw_context.transparent_surfaces.data(), eng.main_draw_context.transparent_surfaces.size());
+    }
+    if (!eng.draw_background() || !eng.draw_geometry()) {
+      fprintf(stderr, "draw failed: %s\n", eng.error.c_str());
+      return 1;
+    }
+  }
+  eng.api.svr_sync(eng.ctx);
+  printf("draws %d triangles %d update %.3f ms record %.3f ms\n", eng.stats.drawcall_count, eng.stats.triangle_count,
+         eng.stats.scene_update_time, eng.stats.mesh_draw_time);
+  if (!prefix.empty()) {
+    std::vector<uint16_t> color;
+    std::vector<float> depth;
+    if (!eng.read_color_rgba16f(color) || !eng.read_depth(depth)) {
+      fprintf(stderr, "readback failed: %s\n", eng.error.c_str());
+      return 1;
+    }
+    dump(prefix + ".color", color.data(), color.size());
+    dump(prefix + ".depth", depth.data(), depth.size());
+  }
+  eng.cleanup();
+  return 0;
+}
