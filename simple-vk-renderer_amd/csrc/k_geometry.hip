@@ -140,6 +140,17 @@ __global__ __launch_bounds__(64) void clip_kernel(FrameParams P) {
       for (int k = 0; k < 3; k++) shade_corner(d, kind, mvp, d.idx[3 * it.tri + k], poly[k]);
     }
     int np = clip_polygon(poly, 3);
+    if (np < 3) continue;
+    // The fan's records are one contiguous block, and the parent's (invalid) main slot links to it:
+    // the tile kernel's visibility pass keeps only (depth, key) per pixel and key - 1 names the main
+    // slot, so shading finds a clipped parent's covering piece through this link.
+    uint32_t want = (uint32_t)(np - 2);
+    uint32_t first = atomicAdd(&P.counters->n_extra, want);
+    if (first + want > P.extra_cap) {
+      atomicOr(&P.counters->overflow, 2u);
+      continue;
+    }
+    uint32_t used = 0;
     for (int i = 1; i + 1 < np; i++) {
       ScreenV s0 = to_screen(poly[0].clip, hw, hh), s1 = to_screen(poly[i].clip, hw, hh),
               s2 = to_screen(poly[i + 1].clip, hw, hh);
@@ -147,16 +158,19 @@ __global__ __launch_bounds__(64) void clip_kernel(FrameParams P) {
       if (!(poly[0].clip[3] > 0.0f && poly[i].clip[3] > 0.0f && poly[i + 1].clip[3] > 0.0f)) continue;
       TriRec tmp;
       if (!setup_triangle(P, &poly[0], &poly[i], &poly[i + 1], s0, s1, s2, seq + 1, d.flags, P.tex[d.tex], &tmp)) continue;
-      uint32_t slot = atomicAdd(&P.counters->n_extra, 1u);
-      if (slot >= P.extra_cap) {
-        atomicOr(&P.counters->overflow, 2u);
-        continue;
-      }
-      uint4* dst = reinterpret_cast<uint4*>(P.recs + P.n_tris + slot);
+      uint4* dst = reinterpret_cast<uint4*>(P.recs + P.n_tris + first + used);
       const uint4* src = reinterpret_cast<const uint4*>(&tmp);
       for (int k = 0; k < 16; k++) dst[k] = src[k];
+      used++;
       if (P.instrument) atomicAdd(&P.counters->binned, 1ull);
     }
+    for (uint32_t k = used; k < want; k++) store_invalid(P.recs + P.n_tris + first + k);  // reserved, unused
+    uint4 link;
+    link.x = 1u;  // minx = 1 > maxx = 0: still an invalid record for binning
+    link.y = 0u;
+    link.z = P.n_tris + first;
+    link.w = used;
+    *reinterpret_cast<uint4*>(P.recs + seq) = link;
   }
 }
 

@@ -341,7 +341,112 @@ __device__ __forceinline__ uint32_t classify(const uint4* s_cov, uint32_t lane, 
          ((cx & 1u) && (cy & 2u) ? 4u : 0u) | ((cx & 2u) && (cy & 2u) ? 8u : 0u);
 }
 
-// Walk one bin (staged through LDS) and update the per-pixel state.
+// ------------------------------------------------------------------------------------------------
+// Phase A, column scan.  A heavy bin is mostly slivers (a distant column's quads are ~3 x 26 pixels)
+// and a whole-wave pass per triangle leaves 95 % of the lanes idle on them.  Instead every triangle of
+// a staged batch is expanded into one work item per pixel column of its tile-clamped bbox (wave prefix
+// sum over the 64 column counts); one lane takes one item, walks its rows and resolves visibility with
+// one LDS ds_max_u64 per covered pixel on a (depth bits << 32 | key) tile.  Lanes are busy whatever
+// the triangle shapes are; the four waves take alternate chunks of 64 items.  max over (depth, key)
+// is what in-order GREATER_OR_EQUAL with depth write leaves behind, so no order is needed.  The
+// record is implied by the key: key - 1 is the triangle's main slot (a clipped parent's slot links to
+// its pieces, see resolve_record).
+template <bool INSTR>
+__device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov, uint32_t bin_base, uint32_t n,
+                                             unsigned long long* s_depth, int tx0, int ty0, uint32_t& n_raster) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (uint32_t b0 = 0; b0 < n; b0 += BATCH) {
+    uint32_t cnt = min((uint32_t)BATCH, n - b0);
+    __syncthreads();  // previous batch fully consumed
+    for (uint32_t piece = threadIdx.x; piece < cnt * 8u; piece += 256u) {
+      uint32_t ri = P.bins[bin_base + b0 + (piece >> 3)];
+      s_cov[piece] = reinterpret_cast<const uint4*>(P.recs + ri)[piece & 7u];
+    }
+    __syncthreads();
+    // lane i: column count of triangle i inside this tile
+    int cx0 = 0, cw = 0;
+    if (lane < cnt) {
+      uint4 h = s_cov[lane * 8u];
+      int minx = (int)(int16_t)(h.x & 0xffffu), miny = (int)(int16_t)(h.x >> 16);
+      int maxx = (int)(int16_t)(h.y & 0xffffu), maxy = (int)(int16_t)(h.y >> 16);
+      cx0 = max(minx, tx0);
+      int cx1 = min(maxx, tx0 + TILE - 1);
+      int cy0 = max(miny, ty0), cy1 = min(maxy, ty0 + TILE - 1);
+      cw = (cx1 >= cx0 && cy1 >= cy0) ? cx1 - cx0 + 1 : 0;
+    }
+    uint32_t inc = (uint32_t)cw;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t v = __shfl_up(inc, off);
+      if ((int)lane >= off) inc += v;
+    }
+    uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    for (uint32_t c = wave; c * 64u < total; c += 4u) {
+      uint32_t j = c * 64u + lane;
+      bool act = j < total;
+      // owner = number of triangles whose inclusive prefix is <= j (binary search over the wave's lanes)
+      uint32_t pos = 0;
+#pragma unroll
+      for (uint32_t step = 32; step >= 1; step >>= 1) {
+        uint32_t v = __shfl(inc, (int)min(pos + step - 1u, 63u));
+        if (pos + step <= 64u && v <= j) pos += step;
+      }
+      uint32_t i = min(pos, 63u);
+      uint32_t excl = __shfl(inc, (int)i) - (uint32_t)__shfl(cw, (int)i);
+      int col = __shfl(cx0, (int)i) + (int)(j - excl);
+      if (!act) continue;
+      const uint4* rec = s_cov + i * 8u;
+      uint4 h = rec[0];
+      int miny = (int)(int16_t)(h.x >> 16), maxy = (int)(int16_t)(h.y >> 16);
+      int y0 = max(miny, ty0), y1 = min(maxy, ty0 + TILE - 1);
+      uint32_t key = h.z, flags = h.w;
+      float4 zr = reinterpret_cast<const float4*>(rec)[1];
+      const double2* d = reinterpret_cast<const double2*>(rec);
+      double2 c2 = d[2], c3 = d[3], c4 = d[4], c5 = d[5], c6 = d[6];
+      double B0 = c3.y, B1 = c4.x, B2 = c4.y;
+      double u1 = (flags & F_T1) ? 1.0 : 0.0, u2 = (flags & F_T2) ? 1.0 : 0.0;
+      double dx = (double)col, dy = (double)y0;
+      double f0 = fma(c2.x, dx, fma(B0, dy, c5.x));
+      double f1 = fma(c2.y, dx, fma(B1, dy, c5.y));
+      double f2 = fma(c3.x, dx, fma(B2, dy, c6.x));
+      unsigned long long* cell = s_depth + (y0 - ty0) * TILE + (col - tx0);
+      for (int y = y0; y <= y1; y++) {
+        if (f0 >= 0.0 && f1 >= 0.0 && f2 >= 0.0) {
+          if (INSTR) n_raster++;
+          float b1 = (float)(f1 + u1) * zr.w, b2 = (float)(f2 + u2) * zr.w;
+          float z = fmaf(b2, zr.z, fmaf(b1, zr.y, zr.x));
+          z = fminf(fmaxf(z, 0.0f), 1.0f) + 0.0f;
+          atomicMax(cell, ((unsigned long long)f2u(z) << 32) | key);
+        }
+        f0 += B0;  // exact: integers below 2^53
+        f1 += B1;
+        f2 += B2;
+        cell += TILE;
+      }
+    }
+  }
+}
+
+// key - 1 is the main record slot.  If that triangle went through the clipper its slot is an invalid
+// record that links to the contiguous block of its pieces (k_geometry.hip clip_kernel); exactly one of
+// them covers the pixel (they partition the parent under the top-left rule).
+__device__ __forceinline__ uint32_t resolve_record(const FrameParams& P, uint32_t rec, int px, int py) {
+  uint4 h = *reinterpret_cast<const uint4*>(P.recs + rec);
+  if ((int)(int16_t)(h.x & 0xffffu) <= (int)(int16_t)(h.y & 0xffffu)) return rec;
+  double dx = (double)px, dy = (double)py;
+  for (uint32_t c = 0; c < h.w; c++) {
+    const TriRec* t = P.recs + h.z + c;
+    if (t->minx > t->maxx || px < t->minx || px > t->maxx || py < t->miny || py > t->maxy) continue;
+    if (fma(t->A[0], dx, fma(t->B[0], dy, t->C[0])) >= 0.0 && fma(t->A[1], dx, fma(t->B[1], dy, t->C[1])) >= 0.0 &&
+        fma(t->A[2], dx, fma(t->B[2], dy, t->C[2])) >= 0.0)
+      return h.z + c;
+  }
+  return rec;  // unreachable for a pixel that produced a fragment
+}
+
+// Walk one bin (staged through LDS) with whole-wave passes and update the per-pixel register state.
+// Used where the record of the winning fragment must be known per pixel and order matters: the
+// transparent pass (ordered walk) and its peeling fallback.
 template <bool PEEL, bool INSTR>
 __device__ __forceinline__ void walk_bin(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, uint32_t bin_base,
                                          uint32_t n, int ox, int oy, int lx, int ly, const bool (&pix_ok)[4],
@@ -556,7 +661,24 @@ __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
 
   // ---- phase A: opaque visibility
   uint32_t n_op = P.tile_count[tile], n_tr = P.tile_count[P.n_tiles + tile];
-  if (n_op) walk_bin<false, INSTR>(P, s_cov, s_idx, P.tile_offset[tile], n_op, ox, oy, lx, ly, pix_ok, zbits, keys, recs, zero4, true, n_raster);
+  if (n_op) {
+    unsigned long long* s_depth = reinterpret_cast<unsigned long long*>(s_c);  // 8 KiB of the phase-C block
+    int tx0 = (int)(P.sx + tx * TILE), ty0 = (int)(P.sy + ty * TILE);
+    for (uint32_t i = threadIdx.x; i < TILE * TILE; i += 256u) s_depth[i] = 0ull;  // ordered by scan_columns' first barrier
+    scan_columns<INSTR>(P, s_cov, P.tile_offset[tile], n_op, s_depth, tx0, ty0, n_raster);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {  // the winners move into the owning lanes' registers
+      int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
+      unsigned long long v = s_depth[(py - ty0) * TILE + (px - tx0)];
+      if ((uint32_t)v != 0u) {
+        zbits[k] = (uint32_t)(v >> 32);
+        keys[k] = (uint32_t)v;
+        recs[k] = resolve_record(P, (uint32_t)v - 1u, px, py);
+      }
+    }
+    __syncthreads();  // the block is reused by phase C
+  }
 
   if (stamps) stamp[1] = clock64();
   // ---- phase B: shade visible pixels once

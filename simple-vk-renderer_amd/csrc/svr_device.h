@@ -24,7 +24,7 @@ constexpr uint32_t F_KIND_SHIFT = 4;     // 2 bits
 constexpr uint32_t F_TRANSPARENT = 256u;
 
 // SVR_OPT_TUNING bits: switch an optimisation off at run time so it can be A/B-timed in one process
-constexpr uint32_t TUNE_NO_TILE_ORDER = 1u;   // tile kernel walks tiles row-major instead of heaviest-first
+constexpr uint32_t TUNE_NO_TILE_ORDER = 1u;        // tile kernel walks tiles row-major instead of heaviest-first
 
 // One draw call (RenderObject after cull+sort), 128 bytes.
 struct DrawDesc {
