@@ -490,27 +490,30 @@ __device__ __forceinline__ void walk_bin(const FrameParams& P, uint4* s_cov, uin
 // ------------------------------------------------------------------------------------------------
 // Transparent pass, ordered form.  Blending is order dependent (the target rounds after every
 // blend), so fragments must reach each pixel in submission order.  The tile's transparent bin is
-// sorted by submission key once (bitonic sort in LDS, written back in place), then walked once;
-// depth-passing fragments are compacted into a per-wave LDS queue with __ballot + prefix popcount,
-// shaded 64 at a time by whichever lanes are free (full lane efficiency however small the
-// triangles are) and blended into the wave's LDS colour block.  Several fragments of one pixel can
-// sit in the same group of 64: they are applied in queue order by electing, per pixel, the lowest
-// pending lane with ds_min (the result of a min does not depend on lane execution order).
-constexpr uint32_t SORT_CAP = 2048;           // bins above this fall back to per-layer peeling
-constexpr uint32_t QUEUE_CAP = 320;           // < 64 carried over + up to 256 new per triangle
-constexpr uint32_t WAVE_C_BYTES = 256 * 8 + QUEUE_CAP * 8 + 256 * 4;  // colour | queue | election slots
+// sorted by submission key once (bitonic sort in LDS, written back in place), then scanned once with
+// the same (triangle, column) items as phase A.  For the order to survive, wave w owns the tile's
+// rows 8w..8w+7: it takes the items of every triangle that touches its band, in bin order, and all
+// its lanes step through the SAME absolute row at the same time — so the fragments of one pixel are
+// appended to the wave's LDS queue in submission order (__ballot + prefix popcount: lane order is
+// item order).  Depth-passing fragments are shaded 64 at a time by whichever lanes are free and
+// blended into the wave's LDS colour band.  Several fragments of one pixel can sit in the same group
+// of 64: they are applied in queue order by electing, per pixel, the lowest pending lane with ds_min
+// (the result of a min does not depend on lane execution order).
+constexpr uint32_t SORT_CAP = 2048;                       // bins above this fall back to per-layer peeling
+constexpr uint32_t QUEUE_CAP = 128;                       // < 64 carried over + up to 64 new per row step
+constexpr uint32_t WAVE_C_BYTES = 256 * 8 + QUEUE_CAP * 8 + 256 * 4;  // colour band | queue | election slots
+constexpr uint32_t PHASE_C_BYTES = 4 * WAVE_C_BYTES + TILE * TILE * 4;  // + the tile's opaque depth bits
 
 template <int FMT, bool INSTR>
 __device__ __forceinline__ void flush_fragments(const FrameParams& P, typename Codec<FMT>::enc_t* col, uint2* q,
-                                                uint32_t* slot, uint32_t& qn, int ox, int oy, uint32_t lane,
+                                                uint32_t* slot, uint32_t& qn, int tx0, int by0, uint32_t lane,
                                                 uint32_t& n_shaded) {
   typedef Codec<FMT> CD;
   uint32_t cnt = min(qn, 64u);
   bool act = lane < cnt;
   uint2 e = q[act ? lane : 0u];
-  uint32_t pix = e.x, rec = e.y;
-  int k = (int)(pix >> 6), l = (int)(pix & 63u);
-  int px = ox + (k & 1) * 8 + (l & 7), py = oy + (k >> 1) * 8 + (l >> 3);
+  uint32_t pix = e.x, rec = e.y;  // pix = row in band * 32 + column in tile
+  int px = tx0 + (int)(pix & 31u), py = by0 + (int)(pix >> 5);
   float4 src = make_float4(0.f, 0.f, 0.f, 0.f);
   if (act) {
     src = shade_pixel<false>(P, rec, px, py, nullptr);
@@ -543,12 +546,13 @@ __device__ __forceinline__ void flush_fragments(const FrameParams& P, typename C
 }
 
 template <int FMT, bool INSTR>
-__device__ __forceinline__ void walk_ordered(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, uint32_t bin_base,
-                                             uint32_t n, int ox, int oy, int lx, int ly, const bool (&pix_ok)[4],
-                                             uint32_t (&zbits)[4], typename Codec<FMT>::enc_t* col, uint2* q,
-                                             uint32_t* slot, uint32_t& n_raster, uint32_t& n_shaded) {
-  const uint32_t lane = threadIdx.x & 63u;
+__device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, uint32_t bin_base,
+                                                     uint32_t n, int tx0, int ty0, const uint32_t* s_z,
+                                                     typename Codec<FMT>::enc_t* col, uint2* q, uint32_t* slot,
+                                                     uint32_t& n_raster, uint32_t& n_shaded) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const unsigned long long below = (1ull << lane) - 1ull;
+  const int by0 = ty0 + 8 * (int)wave, by1 = by0 + 7;  // this wave's rows
   uint32_t qn = 0;
   for (uint32_t b0 = 0; b0 < n; b0 += BATCH) {
     uint32_t cnt = min((uint32_t)BATCH, n - b0);
@@ -559,34 +563,70 @@ __device__ __forceinline__ void walk_ordered(const FrameParams& P, uint4* s_cov,
       if ((piece & 7u) == 0) s_idx[piece >> 3] = ri;
     }
     __syncthreads();
-    uint32_t my_bm = classify(s_cov, lane, cnt, ox, oy);
-    unsigned long long todo = __ballot(my_bm != 0u);
-    while (todo) {  // ascending bit order == submission order inside the sorted batch
-      int i = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      uint32_t bm = (uint32_t)__builtin_amdgcn_readlane((int)my_bm, i);
-      CovTri t = read_cov(s_cov + (uint32_t)i * 8u);
-      uint32_t ri = s_idx[i];
-      // depth-passing pixels of this triangle, via the peel form of the shared coverage code:
-      // with key bounds (0, ~0) it marks exactly the pixels that are covered and pass GREATER_OR_EQUAL
-      uint32_t ck[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-      uint32_t cr[4] = {NO_REC, NO_REC, NO_REC, NO_REC};
-      const uint32_t none[4] = {0u, 0u, 0u, 0u};
-      raster_triangle<true, INSTR>(t, ri, bm, ox + lx, oy + ly, pix_ok, zbits, ck, cr, none, true, n_raster);
+    int cx0 = 0, cw = 0;
+    if (lane < cnt) {
+      uint4 h = s_cov[lane * 8u];
+      int minx = (int)(int16_t)(h.x & 0xffffu), miny = (int)(int16_t)(h.x >> 16);
+      int maxx = (int)(int16_t)(h.y & 0xffffu), maxy = (int)(int16_t)(h.y >> 16);
+      cx0 = max(minx, tx0);
+      int cx1 = min(maxx, tx0 + TILE - 1);
+      cw = (cx1 >= cx0 && min(maxy, by1) >= max(miny, by0)) ? cx1 - cx0 + 1 : 0;
+    }
+    uint32_t inc = (uint32_t)cw;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (!(bm & (1u << k))) continue;  // scalar branch
-        bool pass = cr[k] != NO_REC;
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t v = __shfl_up(inc, off);
+      if ((int)lane >= off) inc += v;
+    }
+    uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    for (uint32_t c = 0; c * 64u < total; c++) {  // every chunk, in order: items are sorted by submission key
+      uint32_t j = c * 64u + lane;
+      bool act = j < total;
+      uint32_t pos = 0;
+#pragma unroll
+      for (uint32_t step = 32; step >= 1; step >>= 1) {
+        uint32_t v = __shfl(inc, (int)min(pos + step - 1u, 63u));
+        if (pos + step <= 64u && v <= j) pos += step;
+      }
+      uint32_t i = min(pos, 63u);
+      uint32_t excl = __shfl(inc, (int)i) - (uint32_t)__shfl(cw, (int)i);
+      int colx = __shfl(cx0, (int)i) + (int)(j - excl) - tx0;  // column inside the tile
+      colx = act ? colx : 0;
+      const uint4* rec = s_cov + i * 8u;
+      uint4 h = rec[0];
+      int y0 = (int)(int16_t)(h.x >> 16), y1 = (int)(int16_t)(h.y >> 16);
+      uint32_t flags = h.w, ri = s_idx[i];
+      float4 zr = reinterpret_cast<const float4*>(rec)[1];
+      const double2* d = reinterpret_cast<const double2*>(rec);
+      double2 c2 = d[2], c3 = d[3], c4 = d[4], c5 = d[5], c6 = d[6];
+      double B0 = c3.y, B1 = c4.x, B2 = c4.y;
+      double u1 = (flags & F_T1) ? 1.0 : 0.0, u2 = (flags & F_T2) ? 1.0 : 0.0;
+      double dx = (double)(tx0 + colx), dy = (double)by0;
+      double f0 = fma(c2.x, dx, fma(B0, dy, c5.x));
+      double f1 = fma(c2.y, dx, fma(B1, dy, c5.y));
+      double f2 = fma(c3.x, dx, fma(B2, dy, c6.x));
+#pragma unroll 1
+      for (int t = 0; t < 8; t++) {  // the same absolute row by0 + t in every lane
+        int y = by0 + t;
+        bool inside = act && y >= y0 && y <= y1 && f0 >= 0.0 && f1 >= 0.0 && f2 >= 0.0;
+        if (INSTR) n_raster += inside ? 1u : 0u;
+        float b1 = (float)(f1 + u1) * zr.w, b2 = (float)(f2 + u2) * zr.w;
+        float z = fmaf(b2, zr.z, fmaf(b1, zr.y, zr.x));
+        z = fminf(fmaxf(z, 0.0f), 1.0f) + 0.0f;
+        bool pass = inside && f2u(z) >= s_z[(y - ty0) * TILE + colx];  // GREATER_OR_EQUAL vs opaque depth, no write
         unsigned long long m = __ballot(pass);
         if (m) {
-          if (pass) q[qn + (uint32_t)__popcll(m & below)] = make_uint2((uint32_t)k * 64u + lane, ri);
+          if (pass) q[qn + (uint32_t)__popcll(m & below)] = make_uint2((uint32_t)(t * TILE + colx), ri);
           qn += (uint32_t)__popcll(m);
+          if (qn >= 64u) flush_fragments<FMT, INSTR>(P, col, q, slot, qn, tx0, by0, lane, n_shaded);
         }
+        f0 += B0;
+        f1 += B1;
+        f2 += B2;
       }
-      while (qn >= 64u) flush_fragments<FMT, INSTR>(P, col, q, slot, qn, ox, oy, lane, n_shaded);
     }
   }
-  while (qn) flush_fragments<FMT, INSTR>(P, col, q, slot, qn, ox, oy, lane, n_shaded);
+  while (qn) flush_fragments<FMT, INSTR>(P, col, q, slot, qn, tx0, by0, lane, n_shaded);
 }
 
 // bitonic sort of the bin's (key << 32 | record) words by all 256 threads, written back in place
@@ -629,8 +669,8 @@ __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
   typedef typename CD::enc_t enc_t;
   __shared__ uint4 s_cov[BATCH * 8];
   __shared__ uint32_t s_idx[BATCH];
-  __shared__ __attribute__((aligned(16))) unsigned char s_c[4 * WAVE_C_BYTES];  // phase C only (22 KiB)
-  static_assert(4 * WAVE_C_BYTES >= SORT_CAP * 8, "sort scratch aliases the phase-C block");
+  __shared__ __attribute__((aligned(16))) unsigned char s_c[PHASE_C_BYTES];  // phase A depth tile, phase C blocks (20 KiB)
+  static_assert(PHASE_C_BYTES >= SORT_CAP * 8 && PHASE_C_BYTES >= TILE * TILE * 8, "sort scratch and depth tile alias the block");
 
   if (P.counters->overflow) return;  // pass is void; the host grows its buffers and replays it
   // Workgroups are dispatched in blockIdx order: walk the tiles heaviest class first (scan_kernel's
@@ -702,24 +742,31 @@ __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
   // ---- phase C: transparent fragments in submission order
   if (n_tr && n_tr <= SORT_CAP) {
     uint32_t tbase = P.tile_offset[P.n_tiles + tile];
+    int tx0 = (int)(P.sx + tx * TILE), ty0 = (int)(P.sy + ty * TILE);
     sort_bin_by_key(P, reinterpret_cast<unsigned long long*>(s_c), tbase, n_tr);
-    unsigned char* mine = s_c + wave * WAVE_C_BYTES;
-    enc_t* col = reinterpret_cast<enc_t*>(mine);
-    uint2* q = reinterpret_cast<uint2*>(mine + 256 * 8);
-    uint32_t* slot = reinterpret_cast<uint32_t*>(mine + 256 * 8 + QUEUE_CAP * 8);
+    uint32_t* s_z = reinterpret_cast<uint32_t*>(s_c + 4 * WAVE_C_BYTES);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 4; k++) {  // owners publish colour and opaque depth of their pixels to the row bands
       int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
       size_t p = (size_t)py * P.W + (size_t)px;
       enc_t c = enc[k];
       if (!dirty[k] && pix_ok[k]) c = reinterpret_cast<const enc_t*>(P.color)[p];  // colour loadOp LOAD
-      col[k * 64 + (int)lane] = c;
-      slot[k * 64 + (int)lane] = 0xffffffffu;
+      int ry = py - ty0, rx = px - tx0;
+      reinterpret_cast<enc_t*>(s_c + (ry >> 3) * WAVE_C_BYTES)[(ry & 7) * TILE + rx] = c;
+      s_z[ry * TILE + rx] = zbits[k];
     }
-    walk_ordered<FMT, INSTR>(P, s_cov, s_idx, tbase, n_tr, ox, oy, lx, ly, pix_ok, zbits, col, q, slot, n_raster, n_shaded);
+    unsigned char* mine = s_c + wave * WAVE_C_BYTES;
+    enc_t* col = reinterpret_cast<enc_t*>(mine);
+    uint2* q = reinterpret_cast<uint2*>(mine + 256 * 8);
+    uint32_t* slot = reinterpret_cast<uint32_t*>(mine + 256 * 8 + QUEUE_CAP * 8);
+    for (uint32_t i = lane; i < 256u; i += 64u) slot[i] = 0xffffffffu;
+    // (the first barrier inside the scan orders these writes)
+    scan_columns_ordered<FMT, INSTR>(P, s_cov, s_idx, tbase, n_tr, tx0, ty0, s_z, col, q, slot, n_raster, n_shaded);
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      enc[k] = col[k * 64 + (int)lane];
+      int ry = oy + (k >> 1) * 8 + ly - ty0, rx = ox + (k & 1) * 8 + lx - tx0;
+      enc[k] = reinterpret_cast<const enc_t*>(s_c + (ry >> 3) * WAVE_C_BYTES)[(ry & 7) * TILE + rx];
       dirty[k] = pix_ok[k];
     }
   } else if (n_tr) {
