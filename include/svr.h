@@ -126,7 +126,7 @@ typedef struct SvrStats {
   float geometry_ms;             /* vertex + clip + setup kernels */
   float binning_ms;              /* bin count + scan + fill kernels */
   float tile_ms;                 /* the tile raster/shade kernel */
-  float reserved1;
+  uint32_t replayed_passes;      /* passes re-run after a queue overflow since svr_create (SVR_OPT_QUEUE_CAPS) */
 } SvrStats;
 
 typedef struct SvrConfig {
@@ -219,8 +219,20 @@ int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint
  * SVR_OPT_TILE_CYCLES: 1 = every tile workgroup records the shader-clock cycles of its phases
  * (svr_debug_read_tile_cycles); five s_memtime reads per tile, off by default.
  * SVR_OPT_TUNING: bit mask that switches individual optimisations OFF (A/B timing inside one
- * process; results are identical either way).  bit0: tile kernel walks tiles row-major instead of heaviest-first. */
-enum SvrOption { SVR_OPT_COUNT_FRAGMENTS = 1, SVR_OPT_KERNEL_TIMING = 2, SVR_OPT_TILE_CYCLES = 3, SVR_OPT_TUNING = 4 };
+ * process; results are identical either way).  bit0: tile kernel walks tiles row-major instead of
+ * heaviest-first.  bit1: geometry + binning run on the caller's stream instead of overlapping the
+ * previous pass's tile stage on an internal stream.
+ * SVR_OPT_QUEUE_CAPS: initial capacity (entries) of the pass-internal queues — clip queue, clipper
+ * output records, bin/pair lists — instead of the generous defaults; 0 restores the defaults.  A pass
+ * that overflows a queue writes nothing, and is replayed with grown queues before its results can be
+ * observed, so results never depend on this (tests set it tiny to exercise the replay). */
+enum SvrOption {
+  SVR_OPT_COUNT_FRAGMENTS = 1,
+  SVR_OPT_KERNEL_TIMING = 2,
+  SVR_OPT_TILE_CYCLES = 3,
+  SVR_OPT_TUNING = 4,
+  SVR_OPT_QUEUE_CAPS = 5
+};
 int svr_set_option(SvrContext* ctx, int option, int64_t value);
 
 /* Parity test hook: ask the next instrumented pass (SVR_OPT_COUNT_FRAGMENTS = 1) to record the

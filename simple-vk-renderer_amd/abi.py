@@ -42,7 +42,7 @@ class SvrStats(C.Structure):  # src/vk_engine.h:16-22 + extensions
                 ("shaded_fragments", C.c_uint64), ("rasterized_fragments", C.c_uint64),
                 ("binned_triangles", C.c_uint64), ("bin_entries", C.c_uint64),
                 ("geometry_ms", C.c_float), ("binning_ms", C.c_float), ("tile_ms", C.c_float),
-                ("reserved1", C.c_float)]
+                ("replayed_passes", C.c_uint32)]
 
 
 class SvrConfig(C.Structure):
@@ -69,6 +69,7 @@ OPT_COUNT_FRAGMENTS = 1
 OPT_KERNEL_TIMING = 2
 OPT_TILE_CYCLES = 3
 OPT_TUNING = 4
+OPT_QUEUE_CAPS = 5
 
 # every symbol include/svr.h declares
 SYMBOLS = ["svr_create", "svr_destroy", "svr_set_stream", "svr_bind_targets", "svr_get_targets",

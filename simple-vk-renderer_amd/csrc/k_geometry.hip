@@ -11,6 +11,7 @@
 // vertices (DESIGN.md "Geometry").  Triangles that need real clipping (any vertex beyond the
 // near/far planes or the guard band) are queued and handled by clip_kernel so this kernel keeps
 // no polygon arrays in scratch.
+#include "svr_bin.h"
 #include "svr_launch.h"
 
 namespace svr {
@@ -26,58 +27,67 @@ __device__ __forceinline__ void shade_corner(const DrawDesc& d, uint32_t kind, c
 __global__ __launch_bounds__(256) void setup_kernel(FrameParams P) {
   uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   uint32_t lane = threadIdx.x & 63;
-  if (gw >= P.n_chunks) return;
+  if (gw >= P.n_chunks) return;  // wave-uniform
   WaveChunk ch = P.chunks[gw];
   const DrawDesc& d = P.draws[ch.draw];
   uint32_t tri = ch.first_tri + lane;
-  if (tri >= d.tri_count) return;
   uint32_t seq = d.tri_base + tri;
   uint32_t kind = (d.flags >> F_KIND_SHIFT) & 3u;
   TriRec* rec = P.recs + seq;
-
-  VOut v0, v1, v2;
-  if (kind == PIPE_COLORED_TRIANGLE) {
-    colored_triangle_vert(0, v0);
-    colored_triangle_vert(1, v1);
-    colored_triangle_vert(2, v2);
-  } else {
-    float mvp[16];
-    if (kind == PIPE_MESH) {
-      matmul4(P.scene.viewproj, d.mat, mvp);  // sceneData.viewproj * PushConstants.renderMatrix
-    }
-    uint32_t i0 = d.idx[3 * tri + 0], i1 = d.idx[3 * tri + 1], i2 = d.idx[3 * tri + 2];
-    shade_corner(d, kind, mvp, i0, v0);
-    shade_corner(d, kind, mvp, i1, v1);
-    shade_corner(d, kind, mvp, i2, v2);
-  }
-  int c0 = outcode(v0.clip), c1 = outcode(v1.clip), c2 = outcode(v2.clip);
-  if (c0 & c1 & c2) {
-    store_invalid(rec);
-    return;
-  }
-  float hw = (float)P.W * 0.5f, hh = (float)P.H * 0.5f;
-  if (((c0 | c1 | c2) & (OC_NEAR | OC_FAR)) == 0) {
-    ScreenV s0 = to_screen(v0.clip, hw, hh), s1 = to_screen(v1.clip, hw, hh), s2 = to_screen(v2.clip, hw, hh);
-    if (s0.ok && s1.ok && s2.ok) {
-      if (setup_triangle(P, &v0, &v1, &v2, s0, s1, s2, seq + 1, d.flags, P.tex[d.tex], rec)) {
-        if (P.instrument) atomicAdd(&P.counters->binned, 1ull);
-      } else {
-        store_invalid(rec);
+  TriGeom g{};
+  bool ok = false;  // a valid record was written and is to be binned
+  if (tri < d.tri_count) {
+    VOut v0, v1, v2;
+    if (kind == PIPE_COLORED_TRIANGLE) {
+      colored_triangle_vert(0, v0);
+      colored_triangle_vert(1, v1);
+      colored_triangle_vert(2, v2);
+    } else {
+      float mvp[16];
+      if (kind == PIPE_MESH) {
+        matmul4(P.scene.viewproj, d.mat, mvp);  // sceneData.viewproj * PushConstants.renderMatrix
       }
-      return;
+      uint32_t i0 = d.idx[3 * tri + 0], i1 = d.idx[3 * tri + 1], i2 = d.idx[3 * tri + 2];
+      shade_corner(d, kind, mvp, i0, v0);
+      shade_corner(d, kind, mvp, i1, v1);
+      shade_corner(d, kind, mvp, i2, v2);
+    }
+    int c0 = outcode(v0.clip), c1 = outcode(v1.clip), c2 = outcode(v2.clip);
+    bool to_clip = false;
+    if ((c0 & c1 & c2) == 0) {
+      to_clip = true;
+      if (((c0 | c1 | c2) & (OC_NEAR | OC_FAR)) == 0) {
+        float hw = (float)P.W * 0.5f, hh = (float)P.H * 0.5f;
+        ScreenV s0 = to_screen(v0.clip, hw, hh), s1 = to_screen(v1.clip, hw, hh), s2 = to_screen(v2.clip, hw, hh);
+        if (s0.ok && s1.ok && s2.ok) {
+          to_clip = false;
+          ok = setup_triangle(P, &v0, &v1, &v2, s0, s1, s2, seq + 1, d.flags, P.tex[d.tex], rec, &g);
+        }
+      }
+    }
+    if (!ok) store_invalid(rec);
+    if (ok && P.instrument) atomicAdd(&P.counters->binned, 1ull);
+    if (to_clip) {  // slow path: hand over to the clipper (it links its pieces from this slot)
+      uint32_t slot = atomicAdd(&P.counters->n_clip, 1u);
+      if (slot < P.clip_cap) {
+        ClipItem it;
+        it.draw = ch.draw;
+        it.tri = tri;
+        P.clip_queue[slot] = it;
+      } else {
+        atomicOr(&P.counters->overflow, 1u);
+      }
     }
   }
-  // slow path: hand over to the clipper
-  store_invalid(rec);
-  uint32_t slot = atomicAdd(&P.counters->n_clip, 1u);
-  if (slot < P.clip_cap) {
-    ClipItem it;
-    it.draw = ch.draw;
-    it.tri = tri;
-    P.clip_queue[slot] = it;
-  } else {
-    atomicOr(&P.counters->overflow, 1u);
-  }
+  // Emit the triangle's (bin, record) pairs now, while bbox and edge functions are in registers.
+  // Triangles over 16 tiles are queued instead; bin_rest (k_bin.hip) walks those wave-wide.
+  TileRange tr = tile_range(P, g.minx, g.miny, g.maxx, g.maxy, ok);
+  if (ok && tr.nt > SMALL_MAX_TILES) P.big_queue[atomicAdd(&P.counters->n_big, 1u)] = seq;
+  EdgeSet e;
+  e.A0 = g.A[0]; e.A1 = g.A[1]; e.A2 = g.A[2]; e.B0 = g.B[0]; e.B1 = g.B[1]; e.B2 = g.B[2];
+  e.C0 = g.C[0]; e.C1 = g.C[1]; e.C2 = g.C[2];
+  emit_small_pairs(P, ok && tr.nt <= SMALL_MAX_TILES, tr, g.minx, g.miny, g.maxx, g.maxy,
+                   (d.flags & F_TRANSPARENT) ? P.n_tiles : 0u, e, seq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -122,6 +132,8 @@ __device__ int clip_polygon(VOut* poly, int n) {
 
 // One lane per queued triangle, grid-stride over the device-side queue length.
 __global__ __launch_bounds__(64) void clip_kernel(FrameParams P) {
+  // the setup kernel is complete (stream order): freeze the length of its part of the pair list
+  if (blockIdx.x == 0 && threadIdx.x == 0) P.counters->n_pairs_setup = min(P.counters->n_pairs, P.bin_cap);
   uint32_t n = min(P.counters->n_clip, P.clip_cap);
   float hw = (float)P.W * 0.5f, hh = (float)P.H * 0.5f;
   for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(64) void clip_kernel(FrameParams P) {
       if (!(s0.ok && s1.ok && s2.ok)) continue;
       if (!(poly[0].clip[3] > 0.0f && poly[i].clip[3] > 0.0f && poly[i + 1].clip[3] > 0.0f)) continue;
       TriRec tmp;
-      if (!setup_triangle(P, &poly[0], &poly[i], &poly[i + 1], s0, s1, s2, seq + 1, d.flags, P.tex[d.tex], &tmp)) continue;
+      if (!setup_triangle(P, &poly[0], &poly[i], &poly[i + 1], s0, s1, s2, seq + 1, d.flags, P.tex[d.tex], &tmp, nullptr)) continue;
       uint4* dst = reinterpret_cast<uint4*>(P.recs + P.n_tris + first + used);
       const uint4* src = reinterpret_cast<const uint4*>(&tmp);
       for (int k = 0; k < 16; k++) dst[k] = src[k];

@@ -11,14 +11,16 @@
 
 namespace svr {
 
-__global__ __launch_bounds__(256) void fill16f_kernel(uint4* dst, uint32_t n_vec, uint32_t n_pixels, uint2 px) {
+__global__ __launch_bounds__(256) void fill16f_kernel(uint4* dst, uint32_t n_vec, uint32_t n_pixels, uint2 px, const uint32_t* poison) {
+  if (*poison) return;  // an earlier pass is waiting for its replay: the host replays this clear after it
   // two RGBA16F pixels per 16-byte store
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += gridDim.x * blockDim.x)
     dst[i] = make_uint4(px.x, px.y, px.x, px.y);
   if (blockIdx.x == 0 && threadIdx.x == 0 && (n_pixels & 1u))
     reinterpret_cast<uint2*>(dst)[n_pixels - 1] = px;
 }
-__global__ __launch_bounds__(256) void fill8_kernel(uint32_t* dst, uint32_t n_pixels, uint32_t px) {
+__global__ __launch_bounds__(256) void fill8_kernel(uint32_t* dst, uint32_t n_pixels, uint32_t px, const uint32_t* poison) {
+  if (*poison) return;
   uint32_t n_vec = n_pixels >> 2;
   uint4* d4 = reinterpret_cast<uint4*>(dst);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += gridDim.x * blockDim.x)
@@ -31,14 +33,15 @@ static inline uint32_t stream_grid(uint32_t n_items) {
   return g < 1u ? 1u : (g > 2048u ? 2048u : g);
 }
 
-void launch_fill_color(void* color, uint32_t n_pixels, int color_format, uint64_t packed_pixel, hipStream_t s) {
+void launch_fill_color(void* color, uint32_t n_pixels, int color_format, uint64_t packed_pixel, const uint32_t* poison,
+                       hipStream_t s) {
   if (color_format == SVR_COLOR_RGBA16F) {
     uint2 px = make_uint2((uint32_t)packed_pixel, (uint32_t)(packed_pixel >> 32));
     uint32_t n_vec = n_pixels >> 1;
-    hipLaunchKernelGGL(fill16f_kernel, dim3(stream_grid(n_vec)), dim3(256), 0, s, (uint4*)color, n_vec, n_pixels, px);
+    hipLaunchKernelGGL(fill16f_kernel, dim3(stream_grid(n_vec)), dim3(256), 0, s, (uint4*)color, n_vec, n_pixels, px, poison);
   } else {
     hipLaunchKernelGGL(fill8_kernel, dim3(stream_grid(n_pixels >> 2)), dim3(256), 0, s, (uint32_t*)color, n_pixels,
-                       (uint32_t)packed_pixel);
+                       (uint32_t)packed_pixel, poison);
   }
 }
 

@@ -672,7 +672,12 @@ __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
   __shared__ __attribute__((aligned(16))) unsigned char s_c[PHASE_C_BYTES];  // phase A depth tile, phase C blocks (20 KiB)
   static_assert(PHASE_C_BYTES >= SORT_CAP * 8 && PHASE_C_BYTES >= TILE * TILE * 8, "sort scratch and depth tile alias the block");
 
-  if (P.counters->overflow) return;  // pass is void; the host grows its buffers and replays it
+  // A pass that overflowed a queue is void, and so is everything after it until the host has replayed
+  // it (svr_api.hip "the operation log"): the targets stay as they were before the failed pass.
+  if (P.counters->overflow | *P.poison) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.counters->overflow) *P.poison = 1u;
+    return;
+  }
   // Workgroups are dispatched in blockIdx order: walk the tiles heaviest class first (scan_kernel's
   // tile_order).  Tiles are dealt round-robin over the 8 XCDs; a contiguous span per XCD was tried
   // and loses: the heavy rows of the frame all land on one XCD and the other seven idle.

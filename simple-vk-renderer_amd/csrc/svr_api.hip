@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -115,29 +116,57 @@ struct SvrContext {
   DevBuf tex_table;  // TexBinding[materials + 1]; last slot = scratch binding of svr_draw_tex_image
   size_t tex_slots = 0;
 
-  // per-pass device buffers
-  DevBuf d_draws, d_chunks, d_recs, d_clipq, d_tiles, d_bins, d_cvt;
+  // Per-pass device buffers, double-buffered: the geometry+binning stage of pass N+1 runs on the
+  // internal stream `gstream` while the tile stage of pass N still reads set N on the caller's
+  // stream.  ev_bin: set filled (recorded on gstream); ev_tile: set consumed (recorded on `stream`).
+  struct PassSet {
+    DevBuf inputs, recs, clipq, bigq, tiles, bins, pairs;  // inputs = DrawDesc[] then WaveChunk[] (one H2D copy)
+    hipEvent_t ev_bin = nullptr, ev_tile = nullptr;
+    bool used = false;
+  };
+  static const int NSETS = 2;  // three sets were tried: stage 1 is starved by the running tile kernel either way
+  PassSet sets[NSETS];
+  int set_pos = 0;
+  // operation log (see "the operation log" below)
+  struct LoggedOp {
+    bool is_pass = false;
+    int slot = 0;  // index into h_counters / op_done
+    void* clear_rows = nullptr;  // clear: first row, pixel count, format, encoded texel
+    uint32_t clear_pixels = 0;
+    int clear_fmt = 0;
+    uint64_t clear_packed = 0;
+    FrameParams P{};  // pass: parameters as recorded + its draw list
+    std::vector<DrawDesc> draws;
+  };
+  static const int MAX_OPS = 8;
+  std::deque<LoggedOp> log;
+  hipEvent_t op_done[MAX_OPS] = {};
+  int op_pos = 0;
+  uint32_t replayed = 0;         // passes re-run by recover_from_overflow
+  uint32_t* d_poison = nullptr;  // sticky device flag: a pass overflowed, later target writes are void
+  hipStream_t gstream = nullptr;
+  DevBuf d_cvt;
   uint32_t clip_cap = 0, extra_cap = 0, bin_cap = 0;
+  uint32_t debug_caps = 0;  // SVR_OPT_QUEUE_CAPS
   // pinned host staging (ring) + readback
-  static const int RING = 3;
-  void* h_stage[RING] = {nullptr, nullptr, nullptr};
-  size_t h_stage_cap[RING] = {0, 0, 0};
-  hipEvent_t h_stage_ev[RING] = {nullptr, nullptr, nullptr};
-  bool h_stage_used[RING] = {false, false, false};
+  static const int RING = 4;
+  void* h_stage[RING] = {};
+  size_t h_stage_cap[RING] = {};
+  hipEvent_t h_stage_ev[RING] = {};
+  bool h_stage_used[RING] = {};
   int ring_pos = 0;
-  Counters* h_counters = nullptr;
+  Counters* h_counters = nullptr;  // pinned, [MAX_OPS]
 
   hipEvent_t ev_start = nullptr, ev_end = nullptr;
   // SVR_OPT_KERNEL_TIMING: ring of event quadruples (before setup, after clip, after fill, after tiles)
   static const int TRING = 16;
-  hipEvent_t tev[TRING][4] = {};
+  hipEvent_t tev[TRING][5] = {};  // geometry start, after clip, after fill (gstream) | tile start, tile end (stream)
   bool tev_used[TRING] = {};
   int tev_pos = 0;
   bool kernel_timing = false;
   double acc_ms[3] = {0, 0, 0};
   uint32_t acc_n = 0;
-  bool pending = false;      // a pass has been enqueued and not validated yet
-  FrameParams last{};        // parameters of that pass, for replay
+  FrameParams last{};        // parameters of the pass enqueued last (debug read-backs)
   bool instrument = false;
   bool tile_cycles = false;
   uint32_t tuning = 0;
@@ -256,10 +285,11 @@ int stage_slot(SvrContext* ctx, size_t bytes, void** out, int* slot_out) {
 // fold one finished slot of the timing ring into the running means
 int harvest_timing(SvrContext* ctx, int slot) {
   if (!ctx->tev_used[slot]) return SVR_OK;
-  HIPCHK(hipEventSynchronize(ctx->tev[slot][3]));
+  HIPCHK(hipEventSynchronize(ctx->tev[slot][4]));
+  const int from[3] = {0, 1, 3}, to[3] = {1, 2, 4};
   for (int k = 0; k < 3; k++) {
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, ctx->tev[slot][k], ctx->tev[slot][k + 1]));
+    HIPCHK(hipEventElapsedTime(&ms, ctx->tev[slot][from[k]], ctx->tev[slot][to[k]]));
     ctx->acc_ms[k] += ms;
   }
   ctx->acc_n++;
@@ -267,97 +297,216 @@ int harvest_timing(SvrContext* ctx, int slot) {
   return SVR_OK;
 }
 
-int enqueue_pass(SvrContext* ctx, const FrameParams& P) {
-  hipStream_t s = ctx->stream;
+// size the per-pass buffers for P.n_tris and the current capacities, fill the pointers
+int bind_pass_buffers(SvrContext* ctx, FrameParams& P, int set_index) {
+  SvrContext::PassSet& set = ctx->sets[set_index];
+  if (int e = set.recs.ensure(((size_t)P.n_tris + ctx->extra_cap) * sizeof(TriRec))) return e;
+  if (int e = set.clipq.ensure((size_t)ctx->clip_cap * sizeof(ClipItem))) return e;
+  if (int e = set.bigq.ensure(((size_t)P.n_tris + 64) * sizeof(uint32_t))) return e;
+  if (int e = set.tiles.ensure(sizeof(Counters) + ((size_t)P.n_tiles * 5 + 4) * sizeof(uint32_t))) return e;
+  if (int e = set.bins.ensure((size_t)ctx->bin_cap * sizeof(uint32_t))) return e;
+  if (int e = set.pairs.ensure((size_t)ctx->bin_cap * 12)) return e;
+  P.recs = (TriRec*)set.recs.p;
+  P.extra_cap = ctx->extra_cap;
+  P.clip_queue = (ClipItem*)set.clipq.p;
+  P.clip_cap = ctx->clip_cap;
+  P.big_queue = (uint32_t*)set.bigq.p;
+  P.counters = (Counters*)set.tiles.p;
+  P.tile_count = (uint32_t*)((char*)set.tiles.p + sizeof(Counters));
+  P.tile_offset = P.tile_count + (((size_t)P.n_tiles * 2 + 3) & ~(size_t)3);  // 16-byte aligned
+  P.tile_order = P.tile_offset + (size_t)P.n_tiles * 2;
+  P.pairs = (uint2*)set.pairs.p;
+  P.pair_slot = (uint32_t*)((char*)set.pairs.p + (size_t)ctx->bin_cap * 8);
+  P.bins = (uint32_t*)set.bins.p;
+  P.bin_cap = ctx->bin_cap;
+  P.poison = ctx->d_poison;
+  return SVR_OK;
+}
+
+// Enqueue one pass.  Stage 1 (gstream): inputs H2D, memset, setup, clip, bin count, scan, bin fill
+// -> ev_bin.  Stage 2 (caller's stream): wait ev_bin, tile kernel -> ev_tile, counters read-back into
+// *h_out.  The caller sees stream order (everything it enqueued before the call precedes the tile
+// stage, the only one that touches the targets); stage 1 depends on host inputs alone, so it overlaps
+// the tile stages of the passes before it.
+int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& draws, Counters* h_out, bool pipe) {
+  // queue capacities: generous first guesses; overflow -> replay (recover_from_overflow)
+  if (ctx->debug_caps) {  // SVR_OPT_QUEUE_CAPS: start tiny so that tests reach the replay path
+    ctx->clip_cap = std::max<uint32_t>(ctx->clip_cap, ctx->debug_caps);
+    ctx->extra_cap = std::max<uint32_t>(ctx->extra_cap, ctx->debug_caps);
+    ctx->bin_cap = std::max<uint32_t>(ctx->bin_cap, ctx->debug_caps);
+  } else {
+    ctx->clip_cap = std::max<uint32_t>(ctx->clip_cap, std::max<uint32_t>(65536u, P.n_tris / 4u));
+    ctx->extra_cap = std::max<uint32_t>(ctx->extra_cap, std::max<uint32_t>(65536u, P.n_tris / 2u));
+    ctx->bin_cap = std::max<uint32_t>(ctx->bin_cap, std::max<uint32_t>(1u << 22, P.n_tris * 8u));
+  }
+  const int set_index = ctx->set_pos;
+  ctx->set_pos = (ctx->set_pos + 1) % SvrContext::NSETS;
+  SvrContext::PassSet& set = ctx->sets[set_index];
+  hipStream_t s = ctx->stream, g = pipe ? ctx->gstream : ctx->stream;
+  // per-pass inputs: draws + chunks through pinned staging, one copy
+  size_t draw_bytes = draws.size() * sizeof(DrawDesc), chunk_bytes = (size_t)P.n_chunks * sizeof(WaveChunk);
+  if (int e = set.inputs.ensure(std::max<size_t>(draw_bytes + chunk_bytes, 256))) return e;
+  if (int e = bind_pass_buffers(ctx, P, set_index)) return e;
+  // this set was last read by the tile stage of NSETS passes ago
+  if (pipe && set.used) HIPCHK(hipStreamWaitEvent(g, set.ev_tile, 0));
+  void* stage = nullptr;
+  int slot = 0;
+  if (int e = stage_slot(ctx, draw_bytes + chunk_bytes + 64, &stage, &slot)) return e;
+  std::memcpy(stage, draws.data(), draw_bytes);
+  WaveChunk* ch = reinterpret_cast<WaveChunk*>((char*)stage + draw_bytes);
+  size_t ci = 0;
+  for (size_t di = 0; di < draws.size(); di++)
+    for (uint32_t t = 0; t < draws[di].tri_count; t += 64u) {
+      ch[ci].draw = (uint32_t)di;
+      ch[ci].first_tri = t;
+      ci++;
+    }
+  if (draw_bytes + chunk_bytes) HIPCHK(hipMemcpyAsync(set.inputs.p, stage, draw_bytes + chunk_bytes, hipMemcpyHostToDevice, g));
+  HIPCHK(hipEventRecord(ctx->h_stage_ev[slot], g));
+  ctx->h_stage_used[slot] = true;
+  P.draws = (const DrawDesc*)set.inputs.p;
+  P.chunks = (const WaveChunk*)((const char*)set.inputs.p + draw_bytes);  // DrawDesc is 128 B: stays aligned
+
   int ts = -1;
   if (ctx->kernel_timing) {
     ts = ctx->tev_pos;
     ctx->tev_pos = (ctx->tev_pos + 1) % SvrContext::TRING;
     if (int e = harvest_timing(ctx, ts)) return e;
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 5; k++)
       if (!ctx->tev[ts][k]) HIPCHK(hipEventCreate(&ctx->tev[ts][k]));
   }
-  // counters, tile_count and tile_cursor are adjacent in one allocation: one memset node
+  // counters and tile_count are adjacent in one allocation: one memset node
   static_assert(sizeof(Counters) == 64, "Counters is the 64-byte head of the tile buffer");
-  HIPCHK(hipMemsetAsync(P.counters, 0, sizeof(Counters) + (size_t)P.n_tiles * 4 * sizeof(uint32_t), s));
-  HIPCHK(hipEventRecord(ctx->ev_start, s));
-  if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][0], s));
-  launch_setup(P, s);
-  launch_clip(P, s);
-  if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][1], s));
-  launch_bin_count(P, s);
-  launch_bin_scan(P, s);
-  launch_bin_fill(P, s);
-  if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][2], s));
+  HIPCHK(hipMemsetAsync(P.counters, 0, sizeof(Counters) + (size_t)P.n_tiles * 2 * sizeof(uint32_t), g));
+  HIPCHK(hipEventRecord(ctx->ev_start, g));
+  if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][0], g));
+  launch_setup(P, g);
+  launch_clip(P, g);
+  if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][1], g));
+  launch_bin_count(P, g);
+  launch_bin_scan(P, g);
+  launch_bin_fill(P, g);
+  if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][2], g));
+  HIPCHK(hipEventRecord(set.ev_bin, g));
+  if (pipe) HIPCHK(hipStreamWaitEvent(s, set.ev_bin, 0));
+  if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][3], s));
   launch_tiles(P, ctx->fmt, P.instrument != 0, s);
   if (ts >= 0) {
-    HIPCHK(hipEventRecord(ctx->tev[ts][3], s));
+    HIPCHK(hipEventRecord(ctx->tev[ts][4], s));
     ctx->tev_used[ts] = true;
   }
   HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(set.ev_tile, s));
+  set.used = true;
   HIPCHK(hipEventRecord(ctx->ev_end, s));
-  HIPCHK(hipMemcpyAsync(ctx->h_counters, P.counters, sizeof(Counters), hipMemcpyDeviceToHost, s));
-  ctx->pending = true;
+  HIPCHK(hipMemcpyAsync(h_out, P.counters, sizeof(Counters), hipMemcpyDeviceToHost, s));
   ctx->last = P;
   return SVR_OK;
 }
 
-// size the per-pass buffers for P.n_tris and the current capacities, fill the pointers
-int bind_pass_buffers(SvrContext* ctx, FrameParams& P) {
-  if (int e = ctx->d_recs.ensure(((size_t)P.n_tris + ctx->extra_cap) * sizeof(TriRec))) return e;
-  if (int e = ctx->d_clipq.ensure((size_t)ctx->clip_cap * sizeof(ClipItem))) return e;
-  if (int e = ctx->d_tiles.ensure(sizeof(Counters) + (size_t)P.n_tiles * 7 * sizeof(uint32_t))) return e;
-  if (int e = ctx->d_bins.ensure((size_t)ctx->bin_cap * sizeof(uint32_t))) return e;
-  P.recs = (TriRec*)ctx->d_recs.p;
-  P.extra_cap = ctx->extra_cap;
-  P.clip_queue = (ClipItem*)ctx->d_clipq.p;
-  P.clip_cap = ctx->clip_cap;
-  P.counters = (Counters*)ctx->d_tiles.p;
-  P.tile_count = (uint32_t*)((char*)ctx->d_tiles.p + sizeof(Counters));
-  P.tile_cursor = P.tile_count + (size_t)P.n_tiles * 2;
-  P.tile_offset = P.tile_count + (size_t)P.n_tiles * 4;
-  P.tile_order = P.tile_count + (size_t)P.n_tiles * 6;
-  P.bins = (uint32_t*)ctx->d_bins.p;
-  P.bin_cap = ctx->bin_cap;
-  return SVR_OK;
-}
-
-// Wait for the pending pass; if one of its queues overflowed, grow and replay it.
-int finish_pending(SvrContext* ctx) {
-  if (!ctx->pending) return SVR_OK;
-  for (int attempt = 0; attempt < 12; attempt++) {
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    Counters c = *ctx->h_counters;
-    if (c.overflow == 0) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_end) == hipSuccess) ctx->stats.gpu_time_ms = ms;
-      ctx->stats.bin_entries = c.total_entries;
-      if (ctx->last.instrument) {
-        ctx->stats.rasterized_fragments = c.rasterized;
-        ctx->stats.shaded_fragments = c.shaded;
-        ctx->stats.binned_triangles = c.binned;
-      }
-      ctx->pending = false;
-      return SVR_OK;
-    }
-    // buffers can be replaced: the stream is idle
-    if (c.overflow & 1u) ctx->clip_cap = std::max<uint32_t>(ctx->clip_cap * 2u, c.n_clip + 1024u);
-    if (c.overflow & 2u) ctx->extra_cap = std::max<uint32_t>(ctx->extra_cap * 2u, c.n_extra + 1024u);
-    if (c.overflow & 4u) ctx->bin_cap = std::max<uint32_t>(ctx->bin_cap * 2u, c.total_entries + c.total_entries / 4u);
-    FrameParams P = ctx->last;
-    if (int e = bind_pass_buffers(ctx, P)) return e;
-    if (int e = enqueue_pass(ctx, P)) return e;
+void note_pass_stats(SvrContext* ctx, const FrameParams& P, const Counters& c) {
+  ctx->stats.bin_entries = c.total_entries;
+  if (P.instrument) {
+    ctx->stats.rasterized_fragments = c.rasterized;
+    ctx->stats.shaded_fragments = c.shaded;
+    ctx->stats.binned_triangles = c.binned;
   }
-  ctx->pending = false;
-  return fail(SVR_ERR_OVERFLOW, "a pass kept overflowing its internal queues after 12 replays");
 }
 
-// non-blocking: validate the previous pass if it has already completed
-int poll_pending(SvrContext* ctx) {
-  if (!ctx->pending) return SVR_OK;
-  if (hipEventQuery(ctx->ev_end) == hipSuccess) return finish_pending(ctx);
+// ---------------------------------------------------------------- the operation log
+// Passes run asynchronously and several deep, so the host learns of a queue overflow late.  The
+// guarantee "results never depend on queue capacities" is kept like this: the tile kernel of a pass
+// that overflowed writes nothing and raises a sticky device flag (poison); every later target-writing
+// kernel of this context (tile kernels, clears) sees the flag and writes nothing either, so the
+// targets freeze in the state before the failed pass.  The host keeps every target-writing operation
+// in a log until its completion event has fired and its counters were checked; on an overflow it
+// drains the device, lowers the flag, grows the queues and replays the log from the failed operation
+// on, in order.  (Work the caller itself enqueues between passes is not in the log; SvrStats.
+// replayed_passes tells such a caller that a replay happened — see dist.py.)
+int log_slot(SvrContext* ctx, int* slot);
+int retire_ops(SvrContext* ctx, bool blocking);
+
+int submit_clear(SvrContext* ctx, const SvrContext::LoggedOp& op) {
+  launch_fill_color(op.clear_rows, op.clear_pixels, op.clear_fmt, op.clear_packed, ctx->d_poison, ctx->stream);
+  HIPCHK(hipGetLastError());
   return SVR_OK;
 }
+
+int recover_from_overflow(SvrContext* ctx) {
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->gstream));
+  Counters c = ctx->h_counters[ctx->log.front().slot];
+  for (SvrContext::LoggedOp& op : ctx->log) {
+    if (!op.is_pass) {
+      HIPCHK(hipMemsetAsync(ctx->d_poison, 0, sizeof(uint32_t), ctx->stream));
+      if (int e = submit_clear(ctx, op)) return e;
+      continue;
+    }
+    bool done = false;
+    for (int attempt = 0; attempt < 12 && !done; attempt++) {
+      if (c.overflow & 1u) ctx->clip_cap = std::max<uint32_t>(ctx->clip_cap * 2u, c.n_clip + 1024u);
+      if (c.overflow & 2u) ctx->extra_cap = std::max<uint32_t>(ctx->extra_cap * 2u, c.n_extra + 1024u);
+      if (c.overflow & 4u) {
+        uint32_t need = std::max(c.total_entries, c.n_pairs);
+        ctx->bin_cap = std::max<uint32_t>(ctx->bin_cap * 2u, need + need / 4u);
+      }
+      HIPCHK(hipMemsetAsync(ctx->d_poison, 0, sizeof(uint32_t), ctx->stream));
+      if (int e = submit_pass(ctx, op.P, op.draws, &ctx->h_counters[op.slot], false)) return e;
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      c = ctx->h_counters[op.slot];
+      done = c.overflow == 0;
+    }
+    if (!done) {
+      ctx->log.clear();
+      return fail(SVR_ERR_OVERFLOW, "a pass kept overflowing its internal queues after 12 replays");
+    }
+    note_pass_stats(ctx, op.P, c);
+    ctx->replayed++;
+    std::memset(&c, 0, sizeof(c));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->log.clear();
+  return SVR_OK;
+}
+
+// validate finished operations front to back; blocking = wait for all of them (a fence)
+int retire_ops(SvrContext* ctx, bool blocking) {
+  while (!ctx->log.empty()) {
+    SvrContext::LoggedOp& op = ctx->log.front();
+    if (blocking) {
+      HIPCHK(hipEventSynchronize(ctx->op_done[op.slot]));
+    } else {
+      hipError_t q = hipEventQuery(ctx->op_done[op.slot]);
+      if (q == hipErrorNotReady) return SVR_OK;
+      HIPCHK(q);
+    }
+    if (op.is_pass) {
+      const Counters& c = ctx->h_counters[op.slot];
+      if (c.overflow) return recover_from_overflow(ctx);
+      if (ctx->log.size() == 1) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_end) == hipSuccess) ctx->stats.gpu_time_ms = ms;
+      }
+      note_pass_stats(ctx, op.P, c);
+    }
+    ctx->log.pop_front();
+  }
+  return SVR_OK;
+}
+
+// a free slot of the counters/event ring for the next logged operation (waits for the oldest if full)
+int log_slot(SvrContext* ctx, int* slot) {
+  while ((int)ctx->log.size() >= SvrContext::MAX_OPS) {
+    HIPCHK(hipEventSynchronize(ctx->op_done[ctx->log.front().slot]));
+    if (int e = retire_ops(ctx, false)) return e;
+  }
+  *slot = ctx->op_pos;
+  ctx->op_pos = (ctx->op_pos + 1) % SvrContext::MAX_OPS;
+  return SVR_OK;
+}
+
+int finish_pending(SvrContext* ctx) { return retire_ops(ctx, true); }  // the fence
+int poll_pending(SvrContext* ctx) { return retire_ops(ctx, false); }
 
 int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& draws) {
   if (int e = poll_pending(ctx)) return e;
@@ -397,35 +546,21 @@ int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& 
     P.tile_cycles = (uint32_t*)ctx->d_tile_cycles.p;
   }
   if (scene) P.scene = *scene;
-  // capacities: generous first guesses; overflow -> replay (finish_pending)
-  ctx->clip_cap = std::max<uint32_t>(ctx->clip_cap, std::max<uint32_t>(65536u, P.n_tris / 4u));
-  ctx->extra_cap = std::max<uint32_t>(ctx->extra_cap, std::max<uint32_t>(65536u, P.n_tris / 2u));
-  ctx->bin_cap = std::max<uint32_t>(ctx->bin_cap, std::max<uint32_t>(1u << 24, P.n_tris * 8u));
-  // per-pass inputs: draws + chunks through pinned staging
-  size_t draw_bytes = draws.size() * sizeof(DrawDesc), chunk_bytes = n_chunks * sizeof(WaveChunk);
-  if (int e = ctx->d_draws.ensure(std::max<size_t>(draw_bytes, 256))) return e;
-  if (int e = ctx->d_chunks.ensure(std::max<size_t>(chunk_bytes, 256))) return e;
-  if (int e = bind_pass_buffers(ctx, P)) return e;
-  void* stage = nullptr;
   int slot = 0;
-  if (int e = stage_slot(ctx, draw_bytes + chunk_bytes + 64, &stage, &slot)) return e;
-  std::memcpy(stage, draws.data(), draw_bytes);
-  WaveChunk* ch = reinterpret_cast<WaveChunk*>((char*)stage + draw_bytes);
-  size_t ci = 0;
-  for (size_t di = 0; di < draws.size(); di++)
-    for (uint32_t t = 0; t < draws[di].tri_count; t += 64u) {
-      ch[ci].draw = (uint32_t)di;
-      ch[ci].first_tri = t;
-      ci++;
-    }
-  if (draw_bytes) HIPCHK(hipMemcpyAsync(ctx->d_draws.p, stage, draw_bytes, hipMemcpyHostToDevice, ctx->stream));
-  if (chunk_bytes)
-    HIPCHK(hipMemcpyAsync(ctx->d_chunks.p, (char*)stage + draw_bytes, chunk_bytes, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipEventRecord(ctx->h_stage_ev[slot], ctx->stream));
-  ctx->h_stage_used[slot] = true;
-  P.draws = (const DrawDesc*)ctx->d_draws.p;
-  P.chunks = (const WaveChunk*)ctx->d_chunks.p;
-  return enqueue_pass(ctx, P);
+  if (int e = log_slot(ctx, &slot)) return e;
+  ctx->log.emplace_back();
+  SvrContext::LoggedOp& op = ctx->log.back();
+  op.is_pass = true;
+  op.slot = slot;
+  op.P = P;
+  op.draws.swap(draws);
+  std::memset(&ctx->h_counters[slot], 0, sizeof(Counters));
+  if (int e = submit_pass(ctx, op.P, op.draws, &ctx->h_counters[slot], !(ctx->tuning & TUNE_NO_PIPELINE))) {
+    ctx->log.pop_back();
+    return e;
+  }
+  HIPCHK(hipEventRecord(ctx->op_done[slot], ctx->stream));
+  return SVR_OK;
 }
 
 }  // namespace
@@ -470,12 +605,23 @@ int svr_create(const SvrConfig* cfg, SvrContext** out) {
   if ((r = hipMemset(ctx->depth_own, 0, n * 4)) != hipSuccess) return bail(r, "hipMemset(depth)");
   ctx->color = ctx->color_own;
   ctx->depth = ctx->depth_own;
+  // (A high-priority stream was tried for stage 1 and changes nothing: the workgroup dispatcher keeps
+  // feeding the tile kernel that is already running, whatever the queue priority.)
+  if ((r = hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking)) != hipSuccess) return bail(r, "hipStreamCreate");
+  for (int i = 0; i < SvrContext::NSETS; i++) {
+    if ((r = hipEventCreateWithFlags(&ctx->sets[i].ev_bin, hipEventDisableTiming)) != hipSuccess) return bail(r, "hipEventCreate");
+    if ((r = hipEventCreateWithFlags(&ctx->sets[i].ev_tile, hipEventDisableTiming)) != hipSuccess) return bail(r, "hipEventCreate");
+  }
   if ((r = hipEventCreate(&ctx->ev_start)) != hipSuccess) return bail(r, "hipEventCreate");
   if ((r = hipEventCreate(&ctx->ev_end)) != hipSuccess) return bail(r, "hipEventCreate");
   for (int i = 0; i < SvrContext::RING; i++)
     if ((r = hipEventCreateWithFlags(&ctx->h_stage_ev[i], hipEventDisableTiming)) != hipSuccess) return bail(r, "hipEventCreate");
-  if ((r = hipHostMalloc((void**)&ctx->h_counters, sizeof(Counters), hipHostMallocDefault)) != hipSuccess)
+  if ((r = hipHostMalloc((void**)&ctx->h_counters, sizeof(Counters) * SvrContext::MAX_OPS, hipHostMallocDefault)) != hipSuccess)
     return bail(r, "hipHostMalloc");
+  for (int i = 0; i < SvrContext::MAX_OPS; i++)
+    if ((r = hipEventCreateWithFlags(&ctx->op_done[i], hipEventDisableTiming)) != hipSuccess) return bail(r, "hipEventCreate");
+  if ((r = hipMalloc((void**)&ctx->d_poison, 256)) != hipSuccess) return bail(r, "hipMalloc");
+  if ((r = hipMemset(ctx->d_poison, 0, 256)) != hipSuccess) return bail(r, "hipMemset");
   *out = ctx;
   return SVR_OK;
 }
@@ -484,24 +630,34 @@ void svr_destroy(SvrContext* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->gstream) (void)hipStreamSynchronize(ctx->gstream);
   for (auto& m : ctx->meshes) {
     if (m.vtx) (void)hipFree(m.vtx);
     if (m.idx) (void)hipFree(m.idx);
   }
   for (auto& im : ctx->images)
     if (im.base) (void)hipFree(im.base);
-  DevBuf* bufs[] = {&ctx->tex_table, &ctx->d_draws, &ctx->d_chunks, &ctx->d_recs, &ctx->d_clipq,
-                    &ctx->d_tiles,   &ctx->d_bins,  &ctx->d_cvt,    &ctx->d_trace, &ctx->d_tile_cycles};
+  DevBuf* bufs[] = {&ctx->tex_table, &ctx->d_cvt, &ctx->d_trace, &ctx->d_tile_cycles};
+  for (auto& set : ctx->sets) {
+    DevBuf* sb[] = {&set.inputs, &set.recs, &set.clipq, &set.bigq, &set.tiles, &set.bins, &set.pairs};
+    for (DevBuf* b : sb) b->release();
+    if (set.ev_bin) (void)hipEventDestroy(set.ev_bin);
+    if (set.ev_tile) (void)hipEventDestroy(set.ev_tile);
+  }
+  if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < SvrContext::RING; i++) {
     if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
     if (ctx->h_stage_ev[i]) (void)hipEventDestroy(ctx->h_stage_ev[i]);
   }
   if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+  for (int i = 0; i < SvrContext::MAX_OPS; i++)
+    if (ctx->op_done[i]) (void)hipEventDestroy(ctx->op_done[i]);
+  if (ctx->d_poison) (void)hipFree(ctx->d_poison);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
   for (int i = 0; i < SvrContext::TRING; i++)
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 5; k++)
       if (ctx->tev[i][k]) (void)hipEventDestroy(ctx->tev[i][k]);
   if (ctx->color_own) (void)hipFree(ctx->color_own);
   if (ctx->depth_own) (void)hipFree(ctx->depth_own);
@@ -705,8 +861,17 @@ int svr_clear_color(SvrContext* ctx, const float rgba[4]) {
   // whole rows of the scissor (a rank of the multi-GPU path only owns its band)
   size_t px_bytes = ctx->fmt == SVR_COLOR_RGBA16F ? 8 : 4;
   char* first_row = (char*)ctx->color + (size_t)ctx->sy * ctx->W * px_bytes;
-  launch_fill_color(first_row, ctx->W * ctx->sh, ctx->fmt, packed, ctx->stream);
-  HIPCHK(hipGetLastError());
+  int slot = 0;
+  if (int e = log_slot(ctx, &slot)) return e;
+  ctx->log.emplace_back();
+  SvrContext::LoggedOp& op = ctx->log.back();
+  op.slot = slot;
+  op.clear_rows = first_row;
+  op.clear_pixels = ctx->W * ctx->sh;
+  op.clear_fmt = ctx->fmt;
+  op.clear_packed = packed;
+  if (int e = submit_clear(ctx, op)) return e;
+  HIPCHK(hipEventRecord(ctx->op_done[slot], ctx->stream));
   return SVR_OK;
 }
 
@@ -891,6 +1056,14 @@ int svr_set_option(SvrContext* ctx, int option, int64_t value) {
     ctx->tuning = (uint32_t)value;
     return SVR_OK;
   }
+  if (option == SVR_OPT_QUEUE_CAPS) {
+    if (value < 0 || value > (1 << 30)) return fail(SVR_ERR_INVALID_ARGUMENT, "SVR_OPT_QUEUE_CAPS: out of range");
+    if (int e = use_device(ctx)) return e;
+    if (int e = finish_pending(ctx)) return e;
+    ctx->debug_caps = (uint32_t)value;
+    ctx->clip_cap = ctx->extra_cap = ctx->bin_cap = 0;  // the next pass sizes its queues afresh
+    return SVR_OK;
+  }
   if (option == SVR_OPT_TILE_CYCLES) {
     ctx->tile_cycles = value != 0;
     return SVR_OK;
@@ -996,6 +1169,7 @@ int svr_get_stats(SvrContext* ctx, SvrStats* out) {
   for (int i = 0; i < SvrContext::TRING; i++)
     if (int e = harvest_timing(ctx, i)) return e;
   *out = ctx->stats;
+  out->replayed_passes = ctx->replayed;
   out->timed_passes = ctx->acc_n;
   if (ctx->acc_n) {
     out->geometry_ms = (float)(ctx->acc_ms[0] / ctx->acc_n);

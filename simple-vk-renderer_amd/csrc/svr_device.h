@@ -24,7 +24,8 @@ constexpr uint32_t F_KIND_SHIFT = 4;     // 2 bits
 constexpr uint32_t F_TRANSPARENT = 256u;
 
 // SVR_OPT_TUNING bits: switch an optimisation off at run time so it can be A/B-timed in one process
-constexpr uint32_t TUNE_NO_TILE_ORDER = 1u;        // tile kernel walks tiles row-major instead of heaviest-first
+constexpr uint32_t TUNE_NO_TILE_ORDER = 1u;   // tile kernel walks tiles row-major instead of heaviest-first
+constexpr uint32_t TUNE_NO_PIPELINE = 2u;     // geometry+binning on the caller's stream too (no overlap between passes)
 
 // One draw call (RenderObject after cull+sort), 128 bytes.
 struct DrawDesc {
@@ -107,7 +108,11 @@ struct Counters {
   unsigned long long rasterized;
   unsigned long long shaded;
   unsigned long long binned;
-  unsigned long long pad[3];  // 64 bytes: the counters head the tile-counter allocation (one memset)
+  uint32_t n_big;          // triangles over 16 tiles queued by the setup kernel (binned wave-per-record)
+  uint32_t n_pairs;        // (bin, record) pairs appended so far (keeps counting past pair capacity)
+  uint32_t n_pairs_setup;  // n_pairs when the setup kernel had finished (snapshot taken by clip_kernel)
+  uint32_t pad32;
+  unsigned long long pad[1];  // 64 bytes: the counters head the tile-counter allocation (one memset)
 };
 
 struct FrameParams {
@@ -126,10 +131,13 @@ struct FrameParams {
   uint32_t extra_cap;
   ClipItem* clip_queue;
   uint32_t clip_cap;
+  uint32_t* big_queue;            // [n_tris] main records whose bbox spans more than 16 tiles
   // bins
   uint32_t* tile_count;           // [2*n_tiles]: opaque bins then transparent bins
   uint32_t* tile_offset;          // [2*n_tiles]
-  uint32_t* tile_cursor;          // [2*n_tiles]
+  uint32_t* poison;               // sticky per-context flag: an earlier pass overflowed, target writes are void
+  uint2* pairs;                   // [bin_cap] (bin, record): what binning scatters, in emission order
+  uint32_t* pair_slot;            // [bin_cap] position of the pair inside its bin
   uint32_t* tile_order;           // [n_tiles] launch order of the tile kernel, heaviest first
   uint32_t* bins;
   uint32_t bin_cap;
@@ -264,9 +272,15 @@ __device__ __forceinline__ void store_invalid(TriRec* rec) {
 
 // C4..C6: snap, orient, edge functions, attribute deltas.  Returns false when the triangle is
 // dropped (zero area or no pixel centre inside the scissor).
+// what binning needs of a set-up triangle, still in registers
+struct TriGeom {
+  int minx, miny, maxx, maxy;
+  double A[3], B[3], C[3];
+};
+
 __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, const VOut* v1, const VOut* v2,
                                       ScreenV s0, ScreenV s1, ScreenV s2, uint32_t key, uint32_t draw_flags,
-                                      const TexBinding& tex, TriRec* out) {
+                                      const TexBinding& tex, TriRec* out, TriGeom* geom) {
   int X0 = __float2int_rn(s0.xs * 256.0f), Y0 = __float2int_rn(s0.ys * 256.0f);
   int X1 = __float2int_rn(s1.xs * 256.0f), Y1 = __float2int_rn(s1.ys * 256.0f);
   int X2 = __float2int_rn(s2.xs * 256.0f), Y2 = __float2int_rn(s2.ys * 256.0f);
@@ -307,6 +321,13 @@ __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, cons
     if (!top_left && i == 2) flags |= F_T2;
   }
   float inv_area = 1.0f / (float)(double)area2;
+  if (geom) {
+    geom->minx = pminx; geom->miny = pminy; geom->maxx = pmaxx; geom->maxy = pmaxy;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      geom->A[i] = A[i]; geom->B[i] = B[i]; geom->C[i] = C[i];
+    }
+  }
 
   uint4* q = reinterpret_cast<uint4*>(out);
   uint4 h;

@@ -18,7 +18,9 @@ void launch_bin_fill(const FrameParams& P, hipStream_t s);
 void launch_tiles(const FrameParams& P, int color_format, bool count_fragments, hipStream_t s);
 // k_image.hip
 // packed_pixel: the already encoded texel (RGBA16F: 4 halves, RGBA8: low 32 bits)
-void launch_fill_color(void* color, uint32_t n_pixels, int color_format, uint64_t packed_pixel, hipStream_t s);
+// poison: the context's sticky overflow flag (the clear is void while it is raised)
+void launch_fill_color(void* color, uint32_t n_pixels, int color_format, uint64_t packed_pixel, const uint32_t* poison,
+                       hipStream_t s);
 void launch_downsample(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh,
                        hipStream_t s);
 void launch_rgba16f_to_rgba8(const void* src, void* dst, uint32_t n_pixels, hipStream_t s);

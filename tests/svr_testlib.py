@@ -89,13 +89,15 @@ def setup_sponza(lib, width, height, lod=8, tex_size=64, color_format=0, window=
 
 
 def render_sponza(lib, width, height, lod=8, tex_size=64, color_format=0, scissor=None, camera=None,
-                  instances=None, threads=None, instrument=False, trace=None):
+                  instances=None, threads=None, instrument=False, trace=None, queue_caps=None):
     """mesh.vert/mesh.frag over the synthetic atrium (BASELINE configs 3-5 at reduced size)."""
     r, scene, opaque, transparent = setup_sponza(lib, width, height, lod, tex_size, color_format,
                                                  camera=camera, instances=instances)
     if threads and lib.backend == "cpu-oracle":
         lib.lib.svr_oracle_set_threads(r.h, threads)
     r.set_option(1, 1 if (instrument or trace) else 0)
+    if queue_caps is not None:
+        r.set_option(5, queue_caps)  # SVR_OPT_QUEUE_CAPS
     if trace:
         r.trace_pixel(*trace)
     r.clear_color((1, 1, 1, 1))

@@ -65,6 +65,47 @@ def test_config3_sponza_full_geometry_1080p(hip, oracle):
     assert a["stats"].triangle_count > 200000
 
 
+def test_queue_overflow_replays_are_invisible(hip, oracle):
+    """Internal queues (clip queue, clipper records, pair/bin lists) sized far too small: the passes
+    overflow, write nothing, and are replayed with grown queues; the frame is the oracle's."""
+    cam = ((2.5, 1.0, -5.5), 0.2, 1.0)  # inside a column: plenty of clipped triangles
+    b = T.render_sponza(oracle, 320, 180, lod=4, tex_size=64, camera=cam, instrument=True)
+    for caps in (1, 64, 3000):
+        a = T.render_sponza(hip, 320, 180, lod=4, tex_size=64, camera=cam, instrument=True, queue_caps=caps)
+        assert_same(a, b, f"queue caps {caps}")
+
+
+def _unfenced_sequence(lib, caps):
+    cam1, cam2 = ((2.5, 1.0, -5.5), 0.2, 1.0), ((30.0, 8.0, 9.7), -0.3, 3.0)
+    r, scene1, opaque, transparent = T.setup_sponza(lib, 320, 180, lod=4, tex_size=64, camera=cam1)
+    scene2 = S.scene_data_struct(*cam2, 320, 180)
+    if caps is not None:
+        r.set_option(A.OPT_QUEUE_CAPS, caps)
+    r.clear_color((1, 1, 1, 1))
+    r.draw_geometry(scene1, opaque, transparent)
+    r.set_scissor(0, 0, 160, 90)
+    r.clear_color((0.25, 0.5, 0.75, 1.0))
+    r.draw_colored_triangle()
+    r.set_scissor(40, 60, 200, 100)
+    r.draw_geometry(scene2, opaque, transparent)
+    out = T._finish(r)
+    r.close()
+    return out
+
+
+def test_overflow_inside_an_unfenced_sequence(hip, oracle):
+    """Five target-writing operations enqueued without a fence, the first pass overflowing its queues:
+    the later clears and passes must not land on top of a frame that misses it (operation log)."""
+    b = _unfenced_sequence(oracle, None)
+    for caps in (64, 2000):
+        a = _unfenced_sequence(hip, caps)
+        assert_same(a, b, f"unfenced sequence, caps {caps}", stats=False)
+        assert a["stats"].replayed_passes >= 1
+    a = _unfenced_sequence(hip, None)
+    assert_same(a, b, "unfenced sequence, default caps", stats=False)
+    assert a["stats"].replayed_passes == 0
+
+
 def test_rgba8_target(hip, oracle):
     a, b = both(T.render_sponza, hip, oracle, 320, 180, lod=8, tex_size=64, color_format=A.COLOR_RGBA8, instrument=True)
     assert_same(a, b, "config3 rgba8")
