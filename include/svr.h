@@ -114,13 +114,14 @@ typedef struct SvrStats {
   float scene_update_time;  /* not produced by this path */
   float mesh_draw_time;     /* host ms spent inside svr_draw_geometry (CPU record time) */
   /* extensions */
-  float gpu_time_ms;             /* device ms of the last completed pass (hipEvent) */
+  float gpu_time_ms;             /* geometry_ms + binning_ms + tile_ms (0 unless SVR_OPT_KERNEL_TIMING is on) */
   uint32_t culled_draws;         /* opaque draws rejected by is_visible */
   uint32_t timed_passes;         /* passes averaged into the three *_ms fields below */
   uint64_t shaded_fragments;     /* fragment-shader evaluations (no helper lanes) */
   uint64_t rasterized_fragments; /* covered pixel-centre samples that reached the depth test */
   uint64_t binned_triangles;     /* triangles that survived clip/cull/zero-area */
-  uint64_t bin_entries;          /* (triangle, tile) pairs */
+  uint64_t bin_entries;          /* (triangle, tile) pairs; like the three counters above: of the last
+                                  * pass run with SVR_OPT_COUNT_FRAGMENTS (uninstrumented passes report nothing) */
   /* mean device ms per pass since SVR_OPT_KERNEL_TIMING was last set, from hipEvents recorded on
    * the pass's own stream between its kernels */
   float geometry_ms;             /* vertex + clip + setup kernels */

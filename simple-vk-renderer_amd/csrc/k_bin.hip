@@ -2,7 +2,7 @@
 //
 // The rasteriser hardware behind vkCmdDrawIndexed walks each triangle's pixels itself; here the
 // frame is cut into tiles (one workgroup each, k_tile.hip) and every triangle is appended to the
-// bin of every tile it can touch.  count -> exclusive scan -> fill, so bins are contiguous spans of
+// bin of every tile it can touch.  count -> span allocation -> fill, so bins are contiguous spans of
 // one buffer and no per-tile capacity exists.  Bin order is arbitrary (atomics): the tile kernel
 // resolves visibility order-independently and sorts the transparent bins itself.
 // Two bin sets share the arrays: [0,n_tiles) opaque, [n_tiles,2*n_tiles) transparent.
@@ -11,7 +11,9 @@
 // triangle of <= 16 tiles while its bbox and edge functions are in registers, and appends (bin, record)
 // pairs to one list.  count_kernel takes a slot in its bin for every pair (and walks what setup could
 // not take — the clipper's records and the queued big triangles — wave per record, appending their
-// pairs with the slot already taken); scan turns counts into offsets; fill scatters.
+// pairs with the slot already taken); offsets_kernel gives every bin a span; fill scatters.
+#include <algorithm>
+
 #include "svr_bin.h"
 #include "svr_launch.h"
 
@@ -130,122 +132,69 @@ __global__ __launch_bounds__(256) void count_kernel(FrameParams P, uint32_t rest
   }
 }
 
-// bins[offset[bin] + slot] = record, for every pair
-__global__ __launch_bounds__(256) void fill_kernel(FrameParams P) {
+// Bin offsets without a scan: bins need not lie in tile order, only be disjoint spans, so every wave
+// reserves the span of its 64 bins with one atomic on the running total (wave prefix sum inside).
+// The same kernel builds the histogram of tile weight classes for the tile kernel's launch order:
+// class = bit length of (opaque + 2*transparent) entries.
+__device__ __forceinline__ uint32_t weight_class(const FrameParams& P, uint32_t t) {
+  return 32u - (uint32_t)__clz(P.tile_count[t] + 2u * P.tile_count[P.n_tiles + t]);
+}
+
+__global__ __launch_bounds__(256) void offsets_kernel(FrameParams P) {
+  __shared__ uint32_t l_cnt[33];
   if (P.counters->overflow) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t n = 2u * P.n_tiles;
+  if (threadIdx.x < 33) l_cnt[threadIdx.x] = 0;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t v = i < n ? P.tile_count[i] : 0u, inc = v;
+  uint32_t cls = i < P.n_tiles ? weight_class(P, i) : 0u;
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t u = __shfl_up(inc, off);
+    if ((int)lane >= off) inc += u;
+  }
+  uint32_t base = 0;
+  if (lane == 63 && inc) {
+    base = atomicAdd(&P.counters->total_entries, inc);
+    if (base + inc > P.bin_cap) atomicOr(&P.counters->overflow, 4u);
+  }
+  base = __shfl(base, 63);
+  if (i < n) P.tile_offset[i] = base + inc - v;
+  __syncthreads();
+  if (i < P.n_tiles) atomicAdd(&l_cnt[cls], 1u);  // LDS
+  __syncthreads();
+  if (threadIdx.x < 33 && l_cnt[threadIdx.x]) atomicAdd(&P.cls_count[threadIdx.x], l_cnt[threadIdx.x]);
+}
+
+// Tile launch order (blocks that own tiles), then bins[offset[bin] + slot] = record for every pair.
+// Order: heaviest class first (longest-processing-time-first), so the few tiles with hundreds of
+// triangles start at once and the light ones fill in behind them; order inside a class is arbitrary.
+// A block ranks its tiles per class in LDS and takes one span per class from the global cursors.
+__global__ __launch_bounds__(256) void fill_kernel(FrameParams P) {
+  __shared__ uint32_t l_cnt[33], l_base[33];
+  if (P.counters->overflow) return;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x * blockDim.x < P.n_tiles) {  // block-uniform
+    if (threadIdx.x < 33) l_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    bool has = t < P.n_tiles;
+    uint32_t cls = has ? weight_class(P, t) : 0u, rank = 0;
+    if (has) rank = atomicAdd(&l_cnt[cls], 1u);  // LDS
+    __syncthreads();
+    if (threadIdx.x < 33) {
+      uint32_t c = threadIdx.x, before = 0;
+      for (uint32_t h = c + 1; h < 33; h++) before += P.cls_count[h];  // tiles of heavier classes
+      uint32_t mine = l_cnt[c];
+      l_base[c] = before + (mine ? atomicAdd(&P.cls_count[40 + c], mine) : 0u);
+    }
+    __syncthreads();
+    if (has) P.tile_order[l_base[cls] + rank] = t;
+  }
   const uint32_t n = min(P.counters->n_pairs, P.bin_cap);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  for (uint32_t i = t; i < n; i += gridDim.x * blockDim.x) {
     uint2 p = P.pairs[i];
     uint32_t pos = P.tile_offset[p.x] + P.pair_slot[i];
     if (pos < P.bin_cap) P.bins[pos] = p.y;
-  }
-}
-
-// Exclusive scan of tile_count[0 .. 2*n_tiles) by one 1024-thread workgroup, plus the tile launch
-// order for the tile kernel: heaviest class first (longest-processing-time-first), so the few tiles
-// with hundreds of triangles start at once and the light ones fill in behind them.  Class = bit
-// length of (opaque + 2*transparent) entries; order inside a class is arbitrary.
-// Every thread scans 16 consecutive counters (four 16-byte loads) and the block scans the 1024 partial
-// sums: 16K counters (a 4K frame has 16,320) take one sweep, larger grids more with a running carry.
-constexpr int SCAN_PER = 16;
-__global__ __launch_bounds__(1024) void scan_kernel(FrameParams P) {
-  __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t cls_count[33], cls_base[33];
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-  const uint32_t n = 2u * P.n_tiles;  // a 16-byte load may run 2 counters into tile_cursor (same allocation)
-  const unsigned long long below = (1ull << lane) - 1ull;
-  if (tid < 33) cls_count[tid] = 0;
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < n; base += 1024u * SCAN_PER) {
-    uint32_t first = base + tid * SCAN_PER;
-    uint32_t v[SCAN_PER];
-#pragma unroll
-    for (int q = 0; q < SCAN_PER / 4; q++) {
-      uint4 w = first + 4u * q < n ? reinterpret_cast<const uint4*>(P.tile_count + first)[q] : make_uint4(0, 0, 0, 0);
-      v[4 * q + 0] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
-    }
-    uint32_t mine = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER; k++) {
-      if (first + (uint32_t)k >= n) v[k] = 0;
-      mine += v[k];
-    }
-    uint32_t inc = mine;
-    for (int off = 1; off < 64; off <<= 1) {
-      uint32_t u = __shfl_up(inc, off);
-      if ((int)lane >= off) inc += u;
-    }
-    __syncthreads();  // wave_tot of the previous sweep consumed
-    if (lane == 63) wave_tot[wv] = inc;
-    __syncthreads();
-    uint32_t wave_base = 0, total = 0;
-    for (uint32_t w = 0; w < 16; w++) {
-      uint32_t t = wave_tot[w];
-      if (w < wv) wave_base += t;
-      total += t;
-    }
-    uint32_t run = carry + wave_base + inc - mine;
-    uint32_t o[SCAN_PER];
-#pragma unroll
-    for (int k = 0; k < SCAN_PER; k++) {
-      o[k] = run;
-      run += v[k];
-    }
-#pragma unroll
-    for (int q = 0; q < SCAN_PER / 4; q++) {
-      if (first + 4u * q + 3u < n) {
-        reinterpret_cast<uint4*>(P.tile_offset + first)[q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
-      } else {
-        for (int k = 4 * q; k < 4 * q + 4; k++)
-          if (first + (uint32_t)k < n) P.tile_offset[first + (uint32_t)k] = o[k];
-      }
-    }
-    carry += total;
-  }
-  if (tid == 0) {
-    P.counters->total_entries = carry;
-    if (carry > P.bin_cap) atomicOr(&P.counters->overflow, 4u);
-  }
-  // class histogram and placement; the lanes of a wave that share a class share one LDS atomic.
-  // Eight tiles per thread and sweep, their counters loaded up front (one memory round trip).
-  constexpr int CLS_PER = 8;
-  for (int pass = 0; pass < 2; pass++) {
-    for (uint32_t base = 0; base < P.n_tiles; base += 1024u * CLS_PER) {
-      uint32_t cls[CLS_PER];
-#pragma unroll
-      for (int k = 0; k < CLS_PER; k++) {
-        uint32_t t = base + (uint32_t)k * 1024u + tid;
-        cls[k] = t < P.n_tiles ? P.tile_count[t] + 2u * P.tile_count[P.n_tiles + t] : 0u;
-      }
-#pragma unroll
-      for (int k = 0; k < CLS_PER; k++) {
-        uint32_t t = base + (uint32_t)k * 1024u + tid;
-        bool has = t < P.n_tiles;
-        uint32_t mine = 32u - (uint32_t)__clz(cls[k]);
-        unsigned long long todo = __ballot(has);
-        while (todo) {
-          int l = __ffsll((long long)todo) - 1;
-          uint32_t c = __shfl(mine, l);
-          unsigned long long same = __ballot(has && mine == c);
-          uint32_t got = 0;
-          if ((int)lane == l) got = atomicAdd(pass == 0 ? &cls_count[c] : &cls_base[c], (uint32_t)__popcll(same));
-          got = __shfl(got, l);
-          if (pass == 1 && has && mine == c) P.tile_order[got + (uint32_t)__popcll(same & below)] = t;
-          todo &= ~same;
-        }
-      }
-    }
-    __syncthreads();
-    if (pass == 0) {
-      if (tid == 0) {
-        uint32_t run = 0;
-        for (int c = 32; c >= 0; c--) {
-          cls_base[c] = run;
-          run += cls_count[c];
-        }
-      }
-      __syncthreads();
-    }
   }
 }
 
@@ -254,10 +203,11 @@ void launch_bin_count(const FrameParams& P, hipStream_t s) {
   hipLaunchKernelGGL(count_kernel, dim3(rest_blocks + 1024u), dim3(256), 0, s, P, rest_blocks);
 }
 void launch_bin_scan(const FrameParams& P, hipStream_t s) {
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, P);
+  hipLaunchKernelGGL(offsets_kernel, dim3((2u * P.n_tiles + 255u) / 256u), dim3(256), 0, s, P);
 }
 void launch_bin_fill(const FrameParams& P, hipStream_t s) {
-  hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, s, P);
+  uint32_t blocks = std::max(1024u, (P.n_tiles + 255u) / 256u);
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, P);
 }
 
 }  // namespace svr

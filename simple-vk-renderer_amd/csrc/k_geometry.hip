@@ -11,6 +11,8 @@
 // vertices (DESIGN.md "Geometry").  Triangles that need real clipping (any vertex beyond the
 // near/far planes or the guard band) are queued and handled by clip_kernel so this kernel keeps
 // no polygon arrays in scratch.
+#include <algorithm>
+
 #include "svr_bin.h"
 #include "svr_launch.h"
 
@@ -213,6 +215,23 @@ void launch_setup(const FrameParams& P, hipStream_t s) {
   if (P.n_chunks == 0) return;
   uint32_t blocks = (P.n_chunks + 3) / 4;
   hipLaunchKernelGGL(setup_kernel, dim3(blocks), dim3(256), 0, s, P);
+}
+// Pass prologue: pull the pass inputs (DrawDesc[] + WaveChunk[], ~100 KB) out of the pinned staging
+// buffer and zero the pass's counters, in one kernel.  A hipMemcpyAsync here is an SDMA packet with
+// ~20 us of signalling between kernels on the critical chain of every pass, a hipMemsetAsync another
+// launch; the staging memory is device-visible, so sixteen bytes per lane over the host link do it.
+__global__ __launch_bounds__(256) void prologue_kernel(const uint4* host_src, uint4* dst, uint32_t n_copy, uint4* zero,
+                                                       uint32_t n_zero) {
+  const uint32_t stride = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t i = t; i < n_copy; i += stride) dst[i] = host_src[i];
+  for (uint32_t i = t; i < n_zero; i += stride) zero[i] = make_uint4(0, 0, 0, 0);
+}
+
+void launch_prologue(const void* host_src, void* dst, size_t copy_bytes, void* zero, size_t zero_bytes, hipStream_t s) {
+  uint32_t n_copy = (uint32_t)((copy_bytes + 15) / 16), n_zero = (uint32_t)((zero_bytes + 15) / 16);
+  uint32_t blocks = std::min<uint32_t>(256u, (std::max(n_copy, n_zero) + 255u) / 256u);
+  hipLaunchKernelGGL(prologue_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, s, (const uint4*)host_src, (uint4*)dst, n_copy,
+                     (uint4*)zero, n_zero);
 }
 void launch_clip(const FrameParams& P, hipStream_t s) {
   hipLaunchKernelGGL(clip_kernel, dim3(512), dim3(64), 0, s, P);

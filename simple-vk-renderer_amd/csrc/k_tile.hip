@@ -664,20 +664,9 @@ __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned l
 }
 
 template <int FMT, bool INSTR>
-__global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
+__device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, unsigned char* s_c) {
   typedef Codec<FMT> CD;
   typedef typename CD::enc_t enc_t;
-  __shared__ uint4 s_cov[BATCH * 8];
-  __shared__ uint32_t s_idx[BATCH];
-  __shared__ __attribute__((aligned(16))) unsigned char s_c[PHASE_C_BYTES];  // phase A depth tile, phase C blocks (20 KiB)
-  static_assert(PHASE_C_BYTES >= SORT_CAP * 8 && PHASE_C_BYTES >= TILE * TILE * 8, "sort scratch and depth tile alias the block");
-
-  // A pass that overflowed a queue is void, and so is everything after it until the host has replayed
-  // it (svr_api.hip "the operation log"): the targets stay as they were before the failed pass.
-  if (P.counters->overflow | *P.poison) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && P.counters->overflow) *P.poison = 1u;
-    return;
-  }
   // Workgroups are dispatched in blockIdx order: walk the tiles heaviest class first (scan_kernel's
   // tile_order).  Tiles are dealt round-robin over the 8 XCDs; a contiguous span per XCD was tried
   // and loses: the heavy rows of the frame all land on one XCD and the other seven idle.
@@ -840,6 +829,35 @@ __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
   }
 }
 
+template <int FMT, bool INSTR>
+__global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
+  __shared__ uint4 s_cov[BATCH * 8];
+  __shared__ uint32_t s_idx[BATCH];
+  __shared__ __attribute__((aligned(16))) unsigned char s_c[PHASE_C_BYTES];  // phase A depth tile, phase C blocks (20 KiB)
+  static_assert(PHASE_C_BYTES >= SORT_CAP * 8 && PHASE_C_BYTES >= TILE * TILE * 8, "sort scratch and depth tile alias the block");
+
+  // A pass that overflowed a queue is void, and so is everything after it until the host has replayed
+  // it (svr_api.hip "the operation log"): the targets stay as they were before the failed pass.
+  if (P.counters->overflow | *P.poison) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *P.poison == 0u) {  // the first failure: flag + tell the host which pass
+      *P.poison = 1u;
+      __hip_atomic_store(P.host_failed_seq, P.op_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  } else {
+    tile_body<FMT, INSTR>(P, s_cov, s_idx, s_c);
+  }
+}
+
+// Instrumented passes only: the counters go to the host (pinned, device-visible) by a one-wave kernel
+// behind the tile kernel.  (A D2H copy packet there costs ~15 us of stream time; a last-workgroup-
+// reports epilogue in the tile kernel holds every workgroup's slot for an atomic round trip: +15 %.)
+// Uninstrumented passes report nothing: the host learns of an overflow through host_failed_seq.
+__global__ __launch_bounds__(64) void report_kernel(FrameParams P) {
+  if (threadIdx.x < sizeof(Counters) / 4)
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(P.host_counters) + threadIdx.x,
+                       reinterpret_cast<const uint32_t*>(P.counters)[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 void launch_tiles(const FrameParams& P, int color_format, bool count_fragments, hipStream_t s) {
   dim3 grid(P.n_tiles), block(256);
   if (color_format == SVR_COLOR_RGBA16F) {
@@ -853,6 +871,7 @@ void launch_tiles(const FrameParams& P, int color_format, bool count_fragments, 
     else
       hipLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA8, false>), grid, block, 0, s, P);
   }
+  if (count_fragments) hipLaunchKernelGGL(report_kernel, dim3(1), dim3(64), 0, s, P);
 }
 
 }  // namespace svr

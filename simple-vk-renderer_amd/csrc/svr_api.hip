@@ -118,18 +118,21 @@ struct SvrContext {
 
   // Per-pass device buffers, double-buffered: the geometry+binning stage of pass N+1 runs on the
   // internal stream `gstream` while the tile stage of pass N still reads set N on the caller's
-  // stream.  ev_bin: set filled (recorded on gstream); ev_tile: set consumed (recorded on `stream`).
+  // stream.  ev_bin: set filled (recorded on gstream); ev_tile: set consumed (the pass's op_done event).
   struct PassSet {
     DevBuf inputs, recs, clipq, bigq, tiles, bins, pairs;  // inputs = DrawDesc[] then WaveChunk[] (one H2D copy)
-    hipEvent_t ev_bin = nullptr, ev_tile = nullptr;
+    hipEvent_t ev_bin = nullptr;
+    hipEvent_t ev_tile = nullptr;  // not owned: op_done of the pass that used the set last
     bool used = false;
   };
+  static const int MAX_OPS = 8;  // operations in flight (log slots)
   static const int NSETS = 2;  // three sets were tried: stage 1 is starved by the running tile kernel either way
   PassSet sets[NSETS];
   int set_pos = 0;
   // operation log (see "the operation log" below)
   struct LoggedOp {
     bool is_pass = false;
+    uint32_t seq = 0;  // passes: running number, reported by the device if the pass overflows
     int slot = 0;  // index into h_counters / op_done
     void* clear_rows = nullptr;  // clear: first row, pixel count, format, encoded texel
     uint32_t clear_pixels = 0;
@@ -138,26 +141,22 @@ struct SvrContext {
     FrameParams P{};  // pass: parameters as recorded + its draw list
     std::vector<DrawDesc> draws;
   };
-  static const int MAX_OPS = 8;
   std::deque<LoggedOp> log;
   hipEvent_t op_done[MAX_OPS] = {};
   int op_pos = 0;
   uint32_t replayed = 0;         // passes re-run by recover_from_overflow
+  uint32_t next_seq = 1;
+  uint32_t* h_failed_seq = nullptr;  // pinned; written by the tile kernel of the first failing pass
   uint32_t* d_poison = nullptr;  // sticky device flag: a pass overflowed, later target writes are void
   hipStream_t gstream = nullptr;
   DevBuf d_cvt;
   uint32_t clip_cap = 0, extra_cap = 0, bin_cap = 0;
   uint32_t debug_caps = 0;  // SVR_OPT_QUEUE_CAPS
   // pinned host staging (ring) + readback
-  static const int RING = 4;
-  void* h_stage[RING] = {};
-  size_t h_stage_cap[RING] = {};
-  hipEvent_t h_stage_ev[RING] = {};
-  bool h_stage_used[RING] = {};
-  int ring_pos = 0;
+  void* h_stage[MAX_OPS] = {};  // per log slot
+  size_t h_stage_cap[MAX_OPS] = {};
   Counters* h_counters = nullptr;  // pinned, [MAX_OPS]
 
-  hipEvent_t ev_start = nullptr, ev_end = nullptr;
   // SVR_OPT_KERNEL_TIMING: ring of event quadruples (before setup, after clip, after fill, after tiles)
   static const int TRING = 16;
   hipEvent_t tev[TRING][5] = {};  // geometry start, after clip, after fill (gstream) | tile start, tile end (stream)
@@ -265,20 +264,17 @@ bool is_visible(const SvrRenderObject& obj, const float* viewproj) {
 }
 
 // ---------------------------------------------------------------- pass machinery
-int stage_slot(SvrContext* ctx, size_t bytes, void** out, int* slot_out) {
-  int s = ctx->ring_pos;
-  ctx->ring_pos = (ctx->ring_pos + 1) % SvrContext::RING;
-  if (ctx->h_stage_used[s]) HIPCHK(hipEventSynchronize(ctx->h_stage_ev[s]));
-  if (ctx->h_stage_cap[s] < bytes) {
-    if (ctx->h_stage[s]) (void)hipHostFree(ctx->h_stage[s]);
-    ctx->h_stage[s] = nullptr;
-    ctx->h_stage_cap[s] = 0;
+// pinned staging buffer of a log slot (free: the slot's previous operation has been retired)
+int stage_buffer(SvrContext* ctx, int slot, size_t bytes, void** out) {
+  if (ctx->h_stage_cap[slot] < bytes) {
+    if (ctx->h_stage[slot]) (void)hipHostFree(ctx->h_stage[slot]);
+    ctx->h_stage[slot] = nullptr;
+    ctx->h_stage_cap[slot] = 0;
     size_t want = bytes + bytes / 2 + 4096;
-    HIPCHK(hipHostMalloc(&ctx->h_stage[s], want, hipHostMallocDefault));
-    ctx->h_stage_cap[s] = want;
+    HIPCHK(hipHostMalloc(&ctx->h_stage[slot], want, hipHostMallocDefault));
+    ctx->h_stage_cap[slot] = want;
   }
-  *out = ctx->h_stage[s];
-  *slot_out = s;
+  *out = ctx->h_stage[slot];
   return SVR_OK;
 }
 
@@ -297,13 +293,17 @@ int harvest_timing(SvrContext* ctx, int slot) {
   return SVR_OK;
 }
 
+// head of a set's tile buffer: Counters (64 B) + 80 class counters (FrameParams::cls_count), then tile_count
+constexpr size_t TILE_HEAD_BYTES = 64 + 80 * sizeof(uint32_t);
+static_assert(sizeof(Counters) == 64 && TILE_HEAD_BYTES % 16 == 0, "tile buffer head layout");
+
 // size the per-pass buffers for P.n_tris and the current capacities, fill the pointers
 int bind_pass_buffers(SvrContext* ctx, FrameParams& P, int set_index) {
   SvrContext::PassSet& set = ctx->sets[set_index];
   if (int e = set.recs.ensure(((size_t)P.n_tris + ctx->extra_cap) * sizeof(TriRec))) return e;
   if (int e = set.clipq.ensure((size_t)ctx->clip_cap * sizeof(ClipItem))) return e;
   if (int e = set.bigq.ensure(((size_t)P.n_tris + 64) * sizeof(uint32_t))) return e;
-  if (int e = set.tiles.ensure(sizeof(Counters) + ((size_t)P.n_tiles * 5 + 4) * sizeof(uint32_t))) return e;
+  if (int e = set.tiles.ensure(TILE_HEAD_BYTES + ((size_t)P.n_tiles * 5 + 4) * sizeof(uint32_t))) return e;
   if (int e = set.bins.ensure((size_t)ctx->bin_cap * sizeof(uint32_t))) return e;
   if (int e = set.pairs.ensure((size_t)ctx->bin_cap * 12)) return e;
   P.recs = (TriRec*)set.recs.p;
@@ -312,7 +312,8 @@ int bind_pass_buffers(SvrContext* ctx, FrameParams& P, int set_index) {
   P.clip_cap = ctx->clip_cap;
   P.big_queue = (uint32_t*)set.bigq.p;
   P.counters = (Counters*)set.tiles.p;
-  P.tile_count = (uint32_t*)((char*)set.tiles.p + sizeof(Counters));
+  P.cls_count = (uint32_t*)((char*)set.tiles.p + sizeof(Counters));
+  P.tile_count = (uint32_t*)((char*)set.tiles.p + TILE_HEAD_BYTES);
   P.tile_offset = P.tile_count + (((size_t)P.n_tiles * 2 + 3) & ~(size_t)3);  // 16-byte aligned
   P.tile_order = P.tile_offset + (size_t)P.n_tiles * 2;
   P.pairs = (uint2*)set.pairs.p;
@@ -320,15 +321,16 @@ int bind_pass_buffers(SvrContext* ctx, FrameParams& P, int set_index) {
   P.bins = (uint32_t*)set.bins.p;
   P.bin_cap = ctx->bin_cap;
   P.poison = ctx->d_poison;
+  P.host_failed_seq = ctx->h_failed_seq;
   return SVR_OK;
 }
 
 // Enqueue one pass.  Stage 1 (gstream): inputs H2D, memset, setup, clip, bin count, scan, bin fill
-// -> ev_bin.  Stage 2 (caller's stream): wait ev_bin, tile kernel -> ev_tile, counters read-back into
-// *h_out.  The caller sees stream order (everything it enqueued before the call precedes the tile
+// -> ev_bin.  Stage 2 (caller's stream): wait ev_bin, tile kernel, counters to the host
+// (report_kernel) -> op_done.  The caller sees stream order (everything it enqueued before the call precedes the tile
 // stage, the only one that touches the targets); stage 1 depends on host inputs alone, so it overlaps
 // the tile stages of the passes before it.
-int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& draws, Counters* h_out, bool pipe) {
+int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& draws, int op_slot, uint32_t seq, bool pipe) {
   // queue capacities: generous first guesses; overflow -> replay (recover_from_overflow)
   if (ctx->debug_caps) {  // SVR_OPT_QUEUE_CAPS: start tiny so that tests reach the replay path
     ctx->clip_cap = std::max<uint32_t>(ctx->clip_cap, ctx->debug_caps);
@@ -345,13 +347,14 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   hipStream_t s = ctx->stream, g = pipe ? ctx->gstream : ctx->stream;
   // per-pass inputs: draws + chunks through pinned staging, one copy
   size_t draw_bytes = draws.size() * sizeof(DrawDesc), chunk_bytes = (size_t)P.n_chunks * sizeof(WaveChunk);
-  if (int e = set.inputs.ensure(std::max<size_t>(draw_bytes + chunk_bytes, 256))) return e;
+  if (int e = set.inputs.ensure(std::max<size_t>(draw_bytes + chunk_bytes + 16, 256))) return e;
   if (int e = bind_pass_buffers(ctx, P, set_index)) return e;
   // this set was last read by the tile stage of NSETS passes ago
   if (pipe && set.used) HIPCHK(hipStreamWaitEvent(g, set.ev_tile, 0));
   void* stage = nullptr;
-  int slot = 0;
-  if (int e = stage_slot(ctx, draw_bytes + chunk_bytes + 64, &stage, &slot)) return e;
+  if (int e = stage_buffer(ctx, op_slot, draw_bytes + chunk_bytes + 64, &stage)) return e;
+  P.host_counters = &ctx->h_counters[op_slot];
+  P.op_seq = seq;
   std::memcpy(stage, draws.data(), draw_bytes);
   WaveChunk* ch = reinterpret_cast<WaveChunk*>((char*)stage + draw_bytes);
   size_t ci = 0;
@@ -361,9 +364,6 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
       ch[ci].first_tri = t;
       ci++;
     }
-  if (draw_bytes + chunk_bytes) HIPCHK(hipMemcpyAsync(set.inputs.p, stage, draw_bytes + chunk_bytes, hipMemcpyHostToDevice, g));
-  HIPCHK(hipEventRecord(ctx->h_stage_ev[slot], g));
-  ctx->h_stage_used[slot] = true;
   P.draws = (const DrawDesc*)set.inputs.p;
   P.chunks = (const WaveChunk*)((const char*)set.inputs.p + draw_bytes);  // DrawDesc is 128 B: stays aligned
 
@@ -375,10 +375,8 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
     for (int k = 0; k < 5; k++)
       if (!ctx->tev[ts][k]) HIPCHK(hipEventCreate(&ctx->tev[ts][k]));
   }
-  // counters and tile_count are adjacent in one allocation: one memset node
-  static_assert(sizeof(Counters) == 64, "Counters is the 64-byte head of the tile buffer");
-  HIPCHK(hipMemsetAsync(P.counters, 0, sizeof(Counters) + (size_t)P.n_tiles * 2 * sizeof(uint32_t), g));
-  HIPCHK(hipEventRecord(ctx->ev_start, g));
+  // inputs out of the staging buffer + zero the counters, class counters and tile_count (adjacent)
+  launch_prologue(stage, set.inputs.p, draw_bytes + chunk_bytes, P.counters, TILE_HEAD_BYTES + (size_t)P.n_tiles * 2 * sizeof(uint32_t), g);
   if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][0], g));
   launch_setup(P, g);
   launch_clip(P, g);
@@ -387,8 +385,10 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   launch_bin_scan(P, g);
   launch_bin_fill(P, g);
   if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][2], g));
-  HIPCHK(hipEventRecord(set.ev_bin, g));
-  if (pipe) HIPCHK(hipStreamWaitEvent(s, set.ev_bin, 0));
+  if (pipe) {
+    HIPCHK(hipEventRecord(set.ev_bin, g));
+    HIPCHK(hipStreamWaitEvent(s, set.ev_bin, 0));
+  }
   if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][3], s));
   launch_tiles(P, ctx->fmt, P.instrument != 0, s);
   if (ts >= 0) {
@@ -396,21 +396,19 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
     ctx->tev_used[ts] = true;
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(set.ev_tile, s));
+  // the one event of the pass: its counters are on the host, its set and staging buffer are free
+  HIPCHK(hipEventRecord(ctx->op_done[op_slot], s));
+  set.ev_tile = ctx->op_done[op_slot];
   set.used = true;
-  HIPCHK(hipEventRecord(ctx->ev_end, s));
-  HIPCHK(hipMemcpyAsync(h_out, P.counters, sizeof(Counters), hipMemcpyDeviceToHost, s));
   ctx->last = P;
   return SVR_OK;
 }
 
-void note_pass_stats(SvrContext* ctx, const FrameParams& P, const Counters& c) {
+void note_pass_stats(SvrContext* ctx, const FrameParams&, const Counters& c) {  // instrumented passes only
   ctx->stats.bin_entries = c.total_entries;
-  if (P.instrument) {
-    ctx->stats.rasterized_fragments = c.rasterized;
-    ctx->stats.shaded_fragments = c.shaded;
-    ctx->stats.binned_triangles = c.binned;
-  }
+  ctx->stats.rasterized_fragments = c.rasterized;
+  ctx->stats.shaded_fragments = c.shaded;
+  ctx->stats.binned_triangles = c.binned;
 }
 
 // ---------------------------------------------------------------- the operation log
@@ -435,7 +433,7 @@ int submit_clear(SvrContext* ctx, const SvrContext::LoggedOp& op) {
 int recover_from_overflow(SvrContext* ctx) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->gstream));
-  Counters c = ctx->h_counters[ctx->log.front().slot];
+  *ctx->h_failed_seq = 0;
   for (SvrContext::LoggedOp& op : ctx->log) {
     if (!op.is_pass) {
       HIPCHK(hipMemsetAsync(ctx->d_poison, 0, sizeof(uint32_t), ctx->stream));
@@ -443,7 +441,9 @@ int recover_from_overflow(SvrContext* ctx) {
       continue;
     }
     bool done = false;
-    for (int attempt = 0; attempt < 12 && !done; attempt++) {
+    Counters c;
+    std::memset(&c, 0, sizeof(c));
+    for (int attempt = 0; attempt < 13 && !done; attempt++) {
       if (c.overflow & 1u) ctx->clip_cap = std::max<uint32_t>(ctx->clip_cap * 2u, c.n_clip + 1024u);
       if (c.overflow & 2u) ctx->extra_cap = std::max<uint32_t>(ctx->extra_cap * 2u, c.n_extra + 1024u);
       if (c.overflow & 4u) {
@@ -451,54 +451,77 @@ int recover_from_overflow(SvrContext* ctx) {
         ctx->bin_cap = std::max<uint32_t>(ctx->bin_cap * 2u, need + need / 4u);
       }
       HIPCHK(hipMemsetAsync(ctx->d_poison, 0, sizeof(uint32_t), ctx->stream));
-      if (int e = submit_pass(ctx, op.P, op.draws, &ctx->h_counters[op.slot], false)) return e;
+      if (int e = submit_pass(ctx, op.P, op.draws, op.slot, op.seq, false)) return e;
       HIPCHK(hipStreamSynchronize(ctx->stream));
-      c = ctx->h_counters[op.slot];
+      HIPCHK(hipMemcpy(&c, ctx->last.counters, sizeof(Counters), hipMemcpyDeviceToHost));
+      *ctx->h_failed_seq = 0;
       done = c.overflow == 0;
     }
     if (!done) {
       ctx->log.clear();
       return fail(SVR_ERR_OVERFLOW, "a pass kept overflowing its internal queues after 12 replays");
     }
-    note_pass_stats(ctx, op.P, c);
+    if (op.P.instrument) note_pass_stats(ctx, op.P, c);
     ctx->replayed++;
-    std::memset(&c, 0, sizeof(c));
   }
+  HIPCHK(hipMemsetAsync(ctx->d_poison, 0, sizeof(uint32_t), ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->log.clear();
   return SVR_OK;
 }
 
-// validate finished operations front to back; blocking = wait for all of them (a fence)
+// validate finished operations front to back; blocking = wait for all of them (a fence).
+// Clears record no event of their own (an event between two kernels is a bubble in the stream): a
+// clear is done when a pass behind it is, or when the stream has drained.
 int retire_ops(SvrContext* ctx, bool blocking) {
   while (!ctx->log.empty()) {
-    SvrContext::LoggedOp& op = ctx->log.front();
+    size_t k = 0;  // first pass at or behind the front
+    while (k < ctx->log.size() && !ctx->log[k].is_pass) k++;
+    if (k == ctx->log.size()) {  // only clears left
+      if (!blocking) return SVR_OK;
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      ctx->log.clear();
+      return SVR_OK;
+    }
+    const int slot = ctx->log[k].slot;
     if (blocking) {
-      HIPCHK(hipEventSynchronize(ctx->op_done[op.slot]));
+      HIPCHK(hipEventSynchronize(ctx->op_done[slot]));
     } else {
-      hipError_t q = hipEventQuery(ctx->op_done[op.slot]);
+      hipError_t q = hipEventQuery(ctx->op_done[slot]);
       if (q == hipErrorNotReady) return SVR_OK;
       HIPCHK(q);
     }
-    if (op.is_pass) {
-      const Counters& c = ctx->h_counters[op.slot];
-      if (c.overflow) return recover_from_overflow(ctx);
-      if (ctx->log.size() == 1) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_end) == hipSuccess) ctx->stats.gpu_time_ms = ms;
-      }
-      note_pass_stats(ctx, op.P, c);
+    // the device names the first pass that overflowed (tile_kernel); everything from it on is void
+    const uint32_t failed = *(volatile uint32_t*)ctx->h_failed_seq;
+    if (failed != 0 && failed == ctx->log[k].seq) {
+      // the clears in front of the failed pass did land: only it and what follows is replayed
+      ctx->log.erase(ctx->log.begin(), ctx->log.begin() + (long)k);
+      return recover_from_overflow(ctx);
     }
-    ctx->log.pop_front();
+    if (ctx->log[k].P.instrument) note_pass_stats(ctx, ctx->log[k].P, ctx->h_counters[slot]);
+    ctx->log.erase(ctx->log.begin(), ctx->log.begin() + (long)k + 1);
   }
   return SVR_OK;
 }
 
-// a free slot of the counters/event ring for the next logged operation (waits for the oldest if full)
+// a free slot of the counters/event/staging ring for the next logged operation (waits if full)
 int log_slot(SvrContext* ctx, int* slot) {
-  while ((int)ctx->log.size() >= SvrContext::MAX_OPS) {
-    HIPCHK(hipEventSynchronize(ctx->op_done[ctx->log.front().slot]));
+  if ((int)ctx->log.size() >= SvrContext::MAX_OPS) {
     if (int e = retire_ops(ctx, false)) return e;
+    if ((int)ctx->log.size() >= SvrContext::MAX_OPS) {
+      bool any_pass = false;
+      for (const SvrContext::LoggedOp& op : ctx->log) any_pass |= op.is_pass;
+      if (any_pass) {
+        for (const SvrContext::LoggedOp& op : ctx->log)
+          if (op.is_pass) {
+            HIPCHK(hipEventSynchronize(ctx->op_done[op.slot]));
+            break;
+          }
+        if (int e = retire_ops(ctx, false)) return e;
+      } else if (int e = retire_ops(ctx, true)) {
+        return e;
+      }
+    }
   }
   *slot = ctx->op_pos;
   ctx->op_pos = (ctx->op_pos + 1) % SvrContext::MAX_OPS;
@@ -551,15 +574,16 @@ int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& 
   ctx->log.emplace_back();
   SvrContext::LoggedOp& op = ctx->log.back();
   op.is_pass = true;
+  op.seq = ctx->next_seq++;
+  if (ctx->next_seq == 0) ctx->next_seq = 1;
   op.slot = slot;
   op.P = P;
   op.draws.swap(draws);
   std::memset(&ctx->h_counters[slot], 0, sizeof(Counters));
-  if (int e = submit_pass(ctx, op.P, op.draws, &ctx->h_counters[slot], !(ctx->tuning & TUNE_NO_PIPELINE))) {
+  if (int e = submit_pass(ctx, op.P, op.draws, slot, op.seq, !(ctx->tuning & TUNE_NO_PIPELINE))) {
     ctx->log.pop_back();
     return e;
   }
-  HIPCHK(hipEventRecord(ctx->op_done[slot], ctx->stream));
   return SVR_OK;
 }
 
@@ -610,16 +634,13 @@ int svr_create(const SvrConfig* cfg, SvrContext** out) {
   if ((r = hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking)) != hipSuccess) return bail(r, "hipStreamCreate");
   for (int i = 0; i < SvrContext::NSETS; i++) {
     if ((r = hipEventCreateWithFlags(&ctx->sets[i].ev_bin, hipEventDisableTiming)) != hipSuccess) return bail(r, "hipEventCreate");
-    if ((r = hipEventCreateWithFlags(&ctx->sets[i].ev_tile, hipEventDisableTiming)) != hipSuccess) return bail(r, "hipEventCreate");
   }
-  if ((r = hipEventCreate(&ctx->ev_start)) != hipSuccess) return bail(r, "hipEventCreate");
-  if ((r = hipEventCreate(&ctx->ev_end)) != hipSuccess) return bail(r, "hipEventCreate");
-  for (int i = 0; i < SvrContext::RING; i++)
-    if ((r = hipEventCreateWithFlags(&ctx->h_stage_ev[i], hipEventDisableTiming)) != hipSuccess) return bail(r, "hipEventCreate");
   if ((r = hipHostMalloc((void**)&ctx->h_counters, sizeof(Counters) * SvrContext::MAX_OPS, hipHostMallocDefault)) != hipSuccess)
     return bail(r, "hipHostMalloc");
   for (int i = 0; i < SvrContext::MAX_OPS; i++)
     if ((r = hipEventCreateWithFlags(&ctx->op_done[i], hipEventDisableTiming)) != hipSuccess) return bail(r, "hipEventCreate");
+  if ((r = hipHostMalloc((void**)&ctx->h_failed_seq, 64, hipHostMallocDefault)) != hipSuccess) return bail(r, "hipHostMalloc");
+  *ctx->h_failed_seq = 0;
   if ((r = hipMalloc((void**)&ctx->d_poison, 256)) != hipSuccess) return bail(r, "hipMalloc");
   if ((r = hipMemset(ctx->d_poison, 0, 256)) != hipSuccess) return bail(r, "hipMemset");
   *out = ctx;
@@ -642,20 +663,16 @@ void svr_destroy(SvrContext* ctx) {
     DevBuf* sb[] = {&set.inputs, &set.recs, &set.clipq, &set.bigq, &set.tiles, &set.bins, &set.pairs};
     for (DevBuf* b : sb) b->release();
     if (set.ev_bin) (void)hipEventDestroy(set.ev_bin);
-    if (set.ev_tile) (void)hipEventDestroy(set.ev_tile);
   }
   if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
   for (DevBuf* b : bufs) b->release();
-  for (int i = 0; i < SvrContext::RING; i++) {
+  for (int i = 0; i < SvrContext::MAX_OPS; i++)
     if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
-    if (ctx->h_stage_ev[i]) (void)hipEventDestroy(ctx->h_stage_ev[i]);
-  }
   if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
   for (int i = 0; i < SvrContext::MAX_OPS; i++)
     if (ctx->op_done[i]) (void)hipEventDestroy(ctx->op_done[i]);
   if (ctx->d_poison) (void)hipFree(ctx->d_poison);
-  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
-  if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+  if (ctx->h_failed_seq) (void)hipHostFree(ctx->h_failed_seq);
   for (int i = 0; i < SvrContext::TRING; i++)
     for (int k = 0; k < 5; k++)
       if (ctx->tev[i][k]) (void)hipEventDestroy(ctx->tev[i][k]);
@@ -870,9 +887,7 @@ int svr_clear_color(SvrContext* ctx, const float rgba[4]) {
   op.clear_pixels = ctx->W * ctx->sh;
   op.clear_fmt = ctx->fmt;
   op.clear_packed = packed;
-  if (int e = submit_clear(ctx, op)) return e;
-  HIPCHK(hipEventRecord(ctx->op_done[slot], ctx->stream));
-  return SVR_OK;
+  return submit_clear(ctx, op);
 }
 
 int svr_set_scissor(SvrContext* ctx, uint32_t x, uint32_t y, uint32_t w, uint32_t h) {
@@ -1175,6 +1190,7 @@ int svr_get_stats(SvrContext* ctx, SvrStats* out) {
     out->geometry_ms = (float)(ctx->acc_ms[0] / ctx->acc_n);
     out->binning_ms = (float)(ctx->acc_ms[1] / ctx->acc_n);
     out->tile_ms = (float)(ctx->acc_ms[2] / ctx->acc_n);
+    out->gpu_time_ms = out->geometry_ms + out->binning_ms + out->tile_ms;
   }
   return SVR_OK;
 }

@@ -135,6 +135,10 @@ struct FrameParams {
   // bins
   uint32_t* tile_count;           // [2*n_tiles]: opaque bins then transparent bins
   uint32_t* tile_offset;          // [2*n_tiles]
+  uint32_t* cls_count;            // [80] zeroed per pass: [0,33) tiles per weight class, [40,73) placement cursors
+  Counters* host_counters;        // pinned host copy, written by report_kernel behind the tile kernel
+  uint32_t* host_failed_seq;      // pinned: op_seq of the first pass that overflowed since the last recovery (0 = none)
+  uint32_t op_seq;                // this pass's number in the context's operation log (never 0)
   uint32_t* poison;               // sticky per-context flag: an earlier pass overflowed, target writes are void
   uint2* pairs;                   // [bin_cap] (bin, record): what binning scatters, in emission order
   uint32_t* pair_slot;            // [bin_cap] position of the pair inside its bin
