@@ -187,8 +187,7 @@ def main():
             "shaded_fragments_per_frame": shaded, "rasterized_fragments_per_frame": rasterized,
             "rasterized_fragments_per_s": rasterized * fps,
             "binned_triangles": binned, "bin_entries": entries,
-            "kernel_ms": {"geometry": st.geometry_ms, "binning": st.binning_ms, "tile": st.tile_ms,
-                          "passes": st.timed_passes},
+            "kernel_ms": {"tile": st.tile_ms, "passes": st.timed_passes},
             "roofline": {"bound": "hbm", "kernel": "tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": tile_bytes, "avg_launch_ms": st.tile_ms},

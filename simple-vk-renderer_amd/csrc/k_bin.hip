@@ -188,7 +188,12 @@ __global__ __launch_bounds__(256) void fill_kernel(FrameParams P) {
       l_base[c] = before + (mine ? atomicAdd(&P.cls_count[40 + c], mine) : 0u);
     }
     __syncthreads();
-    if (has) P.tile_order[l_base[cls] + rank] = t;
+    if (has) {
+      uint32_t slot = l_base[cls] + rank;
+      P.tile_order[slot] = t;
+      P.tile_info[2u * slot] = make_uint4(t, P.tile_count[t], P.tile_offset[t], P.tile_count[P.n_tiles + t]);
+      P.tile_info[2u * slot + 1u] = make_uint4(P.tile_offset[P.n_tiles + t], 0u, 0u, 0u);
+    }
   }
   const uint32_t n = min(P.counters->n_pairs, P.bin_cap);
   for (uint32_t i = t; i < n; i += gridDim.x * blockDim.x) {

@@ -118,6 +118,10 @@ __device__ __forceinline__ float interp3(float a0, float da1, float da2, float b
   return fmaf(b2, da2, fmaf(b1, da1, a0)) * r;
 }
 
+// (Tried and dropped, both bit-exact: taking the quad partners' u,v from lanes ^1 / ^8 by DPP when a
+// whole 8x8 block runs whole quads of one triangle — with ~40 triangles per tile almost no block
+// qualifies, -1 %; the 4-pixel loop is VALU-issue-bound at ~500 instructions per pixel, SQ counters
+// in DESIGN.md.)
 template <bool TRACE>
 __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec, int px, int py, float* trace) {
   const TriRec* tr = P.recs + rec;
@@ -188,19 +192,27 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
   int dlo = mip_linear ? min(dhi + 1, q) : dn;
   float us = (fabsf(u) < 8388608.0f) ? u : 0.0f, vs = (fabsf(v) < 8388608.0f) ? v : 0.0f;
   Taps th = level_taps(t, (uint32_t)dhi, linear, us, vs);
-  Taps tl = level_taps(t, (uint32_t)dlo, linear, us, vs);
   const uint8_t* tb = t.base;
   uint32_t h00 = *reinterpret_cast<const uint32_t*>(tb + th.o00), h10 = *reinterpret_cast<const uint32_t*>(tb + th.o10);
   uint32_t h01 = *reinterpret_cast<const uint32_t*>(tb + th.o01), h11 = *reinterpret_cast<const uint32_t*>(tb + th.o11);
-  uint32_t l00 = *reinterpret_cast<const uint32_t*>(tb + tl.o00), l10 = *reinterpret_cast<const uint32_t*>(tb + tl.o10);
-  uint32_t l01 = *reinterpret_cast<const uint32_t*>(tb + tl.o01), l11 = *reinterpret_cast<const uint32_t*>(tb + tl.o11);
+  // The second level only matters where delta != 0 (lerp(H, L, 0) == H exactly): magnified and
+  // NEAREST-mip pixels skip its four taps when no lane of the wave needs them.
+  Taps tl = th;
+  uint32_t l00 = h00, l10 = h10, l01 = h01, l11 = h11;
+  if (__any(delta != 0.0f)) {
+    tl = level_taps(t, (uint32_t)dlo, linear, us, vs);
+    l00 = *reinterpret_cast<const uint32_t*>(tb + tl.o00);
+    l10 = *reinterpret_cast<const uint32_t*>(tb + tl.o10);
+    l01 = *reinterpret_cast<const uint32_t*>(tb + tl.o01);
+    l11 = *reinterpret_cast<const uint32_t*>(tb + tl.o11);
+  }
   float4 tx;
   tx.x = lerpf(bilerp(h00, h10, h01, h11, 0, th.alpha, th.beta), bilerp(l00, l10, l01, l11, 0, tl.alpha, tl.beta), delta);
   tx.y = lerpf(bilerp(h00, h10, h01, h11, 1, th.alpha, th.beta), bilerp(l00, l10, l01, l11, 1, tl.alpha, tl.beta), delta);
   tx.z = lerpf(bilerp(h00, h10, h01, h11, 2, th.alpha, th.beta), bilerp(l00, l10, l01, l11, 2, tl.alpha, tl.beta), delta);
   tx.w = 1.0f;
   if (TRACE) {  // slots shared with the oracle's trace (tests/tools only)
-    trace[0] = (float)hdr.z; trace[1] = b1; trace[2] = b2; trace[3] = r; trace[4] = u; trace[5] = v;
+    trace[0] = (float)(hdr.z >> 1); trace[1] = b1; trace[2] = b2; trace[3] = r; trace[4] = u; trace[5] = v;
     trace[6] = dudx; trace[7] = dvdx; trace[8] = dudy; trace[9] = dvdy; trace[10] = lambda;
     trace[11] = tx.x; trace[12] = tx.y; trace[13] = tx.z;
     trace[26] = hb1; trace[27] = hb2; trace[28] = vb1; trace[29] = vb2; trace[30] = hr; trace[31] = vr;
@@ -381,9 +393,15 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
       if ((int)lane >= off) inc += v;
     }
     uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-    for (uint32_t c = wave; c * 64u < total; c += 4u) {
-      uint32_t j = c * 64u + lane;
-      bool act = j < total;
+    // Few columns (a tile under a couple of large triangles): cut every column into 2 or 4 row bands so
+    // that all four waves share the walk instead of one wave walking 32 rows per lane.
+    const uint32_t sh = total <= 64u ? 2u : (total <= 128u ? 1u : 0u);  // log2(bands)
+    const int band_rows = TILE >> sh;
+    const uint32_t items = total << sh;
+    for (uint32_t c = wave; c * 64u < items; c += 4u) {
+      uint32_t item = c * 64u + lane;
+      uint32_t j = item >> sh, band = item & ((1u << sh) - 1u);
+      bool act = item < items;
       // owner = number of triangles whose inclusive prefix is <= j (binary search over the wave's lanes)
       uint32_t pos = 0;
 #pragma unroll
@@ -398,7 +416,8 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
       const uint4* rec = s_cov + i * 8u;
       uint4 h = rec[0];
       int miny = (int)(int16_t)(h.x >> 16), maxy = (int)(int16_t)(h.y >> 16);
-      int y0 = max(miny, ty0), y1 = min(maxy, ty0 + TILE - 1);
+      int y0 = max(miny, ty0 + (int)band * band_rows), y1 = min(maxy, ty0 + (int)band * band_rows + band_rows - 1);
+      if (y0 > y1) continue;
       uint32_t key = h.z, flags = h.w;
       float4 zr = reinterpret_cast<const float4*>(rec)[1];
       const double2* d = reinterpret_cast<const double2*>(rec);
@@ -427,9 +446,11 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
   }
 }
 
-// key - 1 is the main record slot.  If that triangle went through the clipper its slot is an invalid
-// record that links to the contiguous block of its pieces (k_geometry.hip clip_kernel); exactly one of
-// them covers the pixel (they partition the parent under the top-left rule).
+// (key >> 1) - 1 is the main record slot, and for keys with bit 0 clear that is the record.  Bit 0 set:
+// the triangle went through the clipper, its slot is an invalid record that links to the contiguous
+// block of its pieces (k_geometry.hip clip_kernel); exactly one of them covers the pixel (they
+// partition the parent under the top-left rule).  The flag keeps this dependent load out of the
+// common path.
 __device__ __forceinline__ uint32_t resolve_record(const FrameParams& P, uint32_t rec, int px, int py) {
   uint4 h = *reinterpret_cast<const uint4*>(P.recs + rec);
   if ((int)(int16_t)(h.x & 0xffffu) <= (int)(int16_t)(h.y & 0xffffu)) return rec;
@@ -670,7 +691,18 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
   // Workgroups are dispatched in blockIdx order: walk the tiles heaviest class first (scan_kernel's
   // tile_order).  Tiles are dealt round-robin over the 8 XCDs; a contiguous span per XCD was tried
   // and loses: the heavy rows of the frame all land on one XCD and the other seven idle.
-  uint32_t tile = (P.tuning & TUNE_NO_TILE_ORDER) ? blockIdx.x : P.tile_order[blockIdx.x];
+  // One 32-byte scalar load names the tile and its two bins (fill_kernel wrote it in launch order).
+  uint32_t tile, n_op, n_tr, off_op, off_tr;
+  if (P.tuning & TUNE_NO_TILE_ORDER) {
+    tile = blockIdx.x;
+    n_op = P.tile_count[tile];
+    n_tr = P.tile_count[P.n_tiles + tile];
+    off_op = P.tile_offset[tile];
+    off_tr = P.tile_offset[P.n_tiles + tile];
+  } else {
+    uint4 i0 = P.tile_info[2u * blockIdx.x], i1 = P.tile_info[2u * blockIdx.x + 1u];
+    tile = i0.x; n_op = i0.y; off_op = i0.z; n_tr = i0.w; off_tr = i1.x;
+  }
   uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
   uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   int ox = (int)(P.sx + tx * TILE + (wave & 1u) * 16u), oy = (int)(P.sy + ty * TILE + (wave >> 1) * 16u);
@@ -694,12 +726,11 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
   if (stamps) stamp[0] = clock64();
 
   // ---- phase A: opaque visibility
-  uint32_t n_op = P.tile_count[tile], n_tr = P.tile_count[P.n_tiles + tile];
   if (n_op) {
     unsigned long long* s_depth = reinterpret_cast<unsigned long long*>(s_c);  // 8 KiB of the phase-C block
     int tx0 = (int)(P.sx + tx * TILE), ty0 = (int)(P.sy + ty * TILE);
     for (uint32_t i = threadIdx.x; i < TILE * TILE; i += 256u) s_depth[i] = 0ull;  // ordered by scan_columns' first barrier
-    scan_columns<INSTR>(P, s_cov, P.tile_offset[tile], n_op, s_depth, tx0, ty0, n_raster);
+    scan_columns<INSTR>(P, s_cov, off_op, n_op, s_depth, tx0, ty0, n_raster);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; k++) {  // the winners move into the owning lanes' registers
@@ -708,7 +739,8 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
       if ((uint32_t)v != 0u) {
         zbits[k] = (uint32_t)(v >> 32);
         keys[k] = (uint32_t)v;
-        recs[k] = resolve_record(P, (uint32_t)v - 1u, px, py);
+        uint32_t main_slot = ((uint32_t)v >> 1) - 1u;
+        recs[k] = ((uint32_t)v & 1u) ? resolve_record(P, main_slot, px, py) : main_slot;
       }
     }
     __syncthreads();  // the block is reused by phase C
@@ -735,7 +767,7 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
   if (stamps) stamp[2] = clock64();
   // ---- phase C: transparent fragments in submission order
   if (n_tr && n_tr <= SORT_CAP) {
-    uint32_t tbase = P.tile_offset[P.n_tiles + tile];
+    uint32_t tbase = off_tr;
     int tx0 = (int)(P.sx + tx * TILE), ty0 = (int)(P.sy + ty * TILE);
     sort_bin_by_key(P, reinterpret_cast<unsigned long long*>(s_c), tbase, n_tr);
     uint32_t* s_z = reinterpret_cast<uint32_t*>(s_c + 4 * WAVE_C_BYTES);
@@ -774,7 +806,7 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
         ck[k] = 0xffffffffu;
         cr[k] = NO_REC;
       }
-      walk_bin<true, INSTR>(P, s_cov, s_idx, P.tile_offset[P.n_tiles + tile], n_tr, ox, oy, lx, ly, pix_ok, zbits, ck, cr, last, first, n_raster);
+      walk_bin<true, INSTR>(P, s_cov, s_idx, off_tr, n_tr, ox, oy, lx, ly, pix_ok, zbits, ck, cr, last, first, n_raster);
       first = false;
       int any = (cr[0] != NO_REC) || (cr[1] != NO_REC) || (cr[2] != NO_REC) || (cr[3] != NO_REC);
       if (!__syncthreads_or(any)) break;
@@ -804,13 +836,44 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
 
   if (stamps) stamp[3] = clock64();
   // ---- phase D: write back
+  // A tile that lies inside the scissor and has every pixel written goes out through LDS as whole
+  // rows: 16 bytes per lane, every 128-byte line of the tile's rows written by one instruction.  (A
+  // lane's own pixels are 8-pixel row pieces of four 8x8 blocks: stored directly they reach memory as
+  // 32- and 64-byte partial lines, which the memory side counted as twice the bytes.)
+  const bool whole = pix_ok[0] && pix_ok[1] && pix_ok[2] && pix_ok[3] && dirty[0] && dirty[1] && dirty[2] && dirty[3];
+  const bool aligned = ((P.W | P.sx) & 3u) == 0u;
+  if (__syncthreads_and(whole) && aligned) {  // the barrier also retires phase C's use of the block
+    const int tx0 = (int)(P.sx + tx * TILE), ty0 = (int)(P.sy + ty * TILE);
+    enc_t* lc = reinterpret_cast<enc_t*>(s_c);
+    uint32_t* lz = reinterpret_cast<uint32_t*>(s_c + TILE * TILE * sizeof(enc_t));
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    if (!pix_ok[k]) continue;
-    int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
-    size_t p = (size_t)py * P.W + (size_t)px;
-    P.depth[p] = u2f(zbits[k]);
-    if (dirty[k]) reinterpret_cast<enc_t*>(P.color)[p] = enc[k];
+    for (int k = 0; k < 4; k++) {
+      int ry = oy + (k >> 1) * 8 + ly - ty0, rx = ox + (k & 1) * 8 + lx - tx0;
+      lc[ry * TILE + rx] = enc[k];
+      lz[ry * TILE + rx] = zbits[k];
+    }
+    __syncthreads();
+    {
+      uint32_t row = threadIdx.x >> 3, c = (threadIdx.x & 7u) * 4u;  // 4 depth values per lane
+      uint4 v = *reinterpret_cast<const uint4*>(lz + row * TILE + c);
+      *reinterpret_cast<uint4*>(P.depth + (size_t)(ty0 + (int)row) * P.W + (size_t)(tx0 + (int)c)) = v;
+    }
+    constexpr uint32_t PX = 16u / sizeof(enc_t);  // pixels per 16-byte store
+#pragma unroll
+    for (uint32_t i = threadIdx.x; i < TILE * TILE / PX; i += 256u) {
+      uint32_t row = i / (TILE / PX), c = (i % (TILE / PX)) * PX;
+      uint4 v = *reinterpret_cast<const uint4*>(lc + row * TILE + c);
+      *reinterpret_cast<uint4*>(reinterpret_cast<enc_t*>(P.color) + (size_t)(ty0 + (int)row) * P.W + (size_t)(tx0 + (int)c)) = v;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (!pix_ok[k]) continue;
+      int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
+      size_t p = (size_t)py * P.W + (size_t)px;
+      P.depth[p] = u2f(zbits[k]);
+      if (dirty[k]) reinterpret_cast<enc_t*>(P.color)[p] = enc[k];
+    }
   }
   if (stamps) {
     stamp[4] = clock64();

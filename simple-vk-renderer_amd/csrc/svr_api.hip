@@ -161,8 +161,9 @@ struct SvrContext {
   static const int TRING = 16;
   hipEvent_t tev[TRING][5] = {};  // geometry start, after clip, after fill (gstream) | tile start, tile end (stream)
   bool tev_used[TRING] = {};
+  bool tev_all[TRING] = {};  // the slot holds all five events (level 2), not just the tile pair
   int tev_pos = 0;
-  bool kernel_timing = false;
+  int kernel_timing = 0;  // 0 off, 1 tile kernel only (two events on the caller's stream), 2 all three stages
   double acc_ms[3] = {0, 0, 0};
   uint32_t acc_n = 0;
   FrameParams last{};        // parameters of the pass enqueued last (debug read-backs)
@@ -283,7 +284,7 @@ int harvest_timing(SvrContext* ctx, int slot) {
   if (!ctx->tev_used[slot]) return SVR_OK;
   HIPCHK(hipEventSynchronize(ctx->tev[slot][4]));
   const int from[3] = {0, 1, 3}, to[3] = {1, 2, 4};
-  for (int k = 0; k < 3; k++) {
+  for (int k = ctx->tev_all[slot] ? 0 : 2; k < 3; k++) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, ctx->tev[slot][from[k]], ctx->tev[slot][to[k]]));
     ctx->acc_ms[k] += ms;
@@ -303,7 +304,7 @@ int bind_pass_buffers(SvrContext* ctx, FrameParams& P, int set_index) {
   if (int e = set.recs.ensure(((size_t)P.n_tris + ctx->extra_cap) * sizeof(TriRec))) return e;
   if (int e = set.clipq.ensure((size_t)ctx->clip_cap * sizeof(ClipItem))) return e;
   if (int e = set.bigq.ensure(((size_t)P.n_tris + 64) * sizeof(uint32_t))) return e;
-  if (int e = set.tiles.ensure(TILE_HEAD_BYTES + ((size_t)P.n_tiles * 5 + 4) * sizeof(uint32_t))) return e;
+  if (int e = set.tiles.ensure(TILE_HEAD_BYTES + ((size_t)P.n_tiles * 13 + 8) * sizeof(uint32_t))) return e;
   if (int e = set.bins.ensure((size_t)ctx->bin_cap * sizeof(uint32_t))) return e;
   if (int e = set.pairs.ensure((size_t)ctx->bin_cap * 12)) return e;
   P.recs = (TriRec*)set.recs.p;
@@ -315,7 +316,8 @@ int bind_pass_buffers(SvrContext* ctx, FrameParams& P, int set_index) {
   P.cls_count = (uint32_t*)((char*)set.tiles.p + sizeof(Counters));
   P.tile_count = (uint32_t*)((char*)set.tiles.p + TILE_HEAD_BYTES);
   P.tile_offset = P.tile_count + (((size_t)P.n_tiles * 2 + 3) & ~(size_t)3);  // 16-byte aligned
-  P.tile_order = P.tile_offset + (size_t)P.n_tiles * 2;
+  P.tile_info = (uint4*)(P.tile_offset + (((size_t)P.n_tiles * 2 + 3) & ~(size_t)3));  // 8 words per tile
+  P.tile_order = (uint32_t*)P.tile_info + (size_t)P.n_tiles * 8;
   P.pairs = (uint2*)set.pairs.p;
   P.pair_slot = (uint32_t*)((char*)set.pairs.p + (size_t)ctx->bin_cap * 8);
   P.bins = (uint32_t*)set.bins.p;
@@ -377,14 +379,15 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   }
   // inputs out of the staging buffer + zero the counters, class counters and tile_count (adjacent)
   launch_prologue(stage, set.inputs.p, draw_bytes + chunk_bytes, P.counters, TILE_HEAD_BYTES + (size_t)P.n_tiles * 2 * sizeof(uint32_t), g);
-  if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][0], g));
+  const bool all_stages = ctx->kernel_timing >= 2;
+  if (ts >= 0 && all_stages) HIPCHK(hipEventRecord(ctx->tev[ts][0], g));
   launch_setup(P, g);
   launch_clip(P, g);
-  if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][1], g));
+  if (ts >= 0 && all_stages) HIPCHK(hipEventRecord(ctx->tev[ts][1], g));
   launch_bin_count(P, g);
   launch_bin_scan(P, g);
   launch_bin_fill(P, g);
-  if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][2], g));
+  if (ts >= 0 && all_stages) HIPCHK(hipEventRecord(ctx->tev[ts][2], g));
   if (pipe) {
     HIPCHK(hipEventRecord(set.ev_bin, g));
     HIPCHK(hipStreamWaitEvent(s, set.ev_bin, 0));
@@ -394,6 +397,7 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   if (ts >= 0) {
     HIPCHK(hipEventRecord(ctx->tev[ts][4], s));
     ctx->tev_used[ts] = true;
+    ctx->tev_all[ts] = all_stages;
   }
   HIPCHK(hipGetLastError());
   // the one event of the pass: its counters are on the host, its set and staging buffer are free
@@ -541,7 +545,7 @@ int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& 
     n_tris64 += d.tri_count;
     n_chunks += (d.tri_count + 63u) / 64u;
   }
-  if (n_tris64 >= 0xfffffff0ull) return fail(SVR_ERR_UNSUPPORTED, "more than 2^32 triangles in one pass");
+  if (n_tris64 >= 0x7ffffff0ull) return fail(SVR_ERR_UNSUPPORTED, "more than 2^31 triangles in one pass");
   FrameParams P;
   std::memset(&P, 0, sizeof(P));
   P.color = ctx->color;
@@ -1089,7 +1093,7 @@ int svr_set_option(SvrContext* ctx, int option, int64_t value) {
       if (int e = harvest_timing(ctx, i)) return e;
     ctx->acc_ms[0] = ctx->acc_ms[1] = ctx->acc_ms[2] = 0.0;
     ctx->acc_n = 0;
-    ctx->kernel_timing = value != 0;
+    ctx->kernel_timing = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     return SVR_OK;
   }
   return fail(SVR_ERR_INVALID_ARGUMENT, "svr_set_option: unknown option");

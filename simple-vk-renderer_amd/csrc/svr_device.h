@@ -78,7 +78,7 @@ __host__ __device__ inline uint32_t mip_offset(uint32_t lw, uint32_t lh, uint32_
 // VALU instruction per ~4 cycles, which is also the cost of a 16-lane/clk v_fma_f64.)
 struct TriRec {
   int16_t minx, miny, maxx, maxy;  // inclusive pixel bbox clamped to the scissor; minx>maxx = invalid
-  uint32_t key;                    // submission sequence number + 1
+  uint32_t key;                    // (submission sequence number + 1) << 1 | came-through-the-clipper
   uint32_t flags;
   float z0, dz1, dz2, inv_area;
   double A[3], B[3], C[3];
@@ -142,6 +142,7 @@ struct FrameParams {
   uint32_t* poison;               // sticky per-context flag: an earlier pass overflowed, target writes are void
   uint2* pairs;                   // [bin_cap] (bin, record): what binning scatters, in emission order
   uint32_t* pair_slot;            // [bin_cap] position of the pair inside its bin
+  uint4* tile_info;               // [2*n_tiles] launch slot -> {tile, n_opaque, offset_opaque, n_transparent}, {offset_transparent,-,-,-}
   uint32_t* tile_order;           // [n_tiles] launch order of the tile kernel, heaviest first
   uint32_t* bins;
   uint32_t bin_cap;

@@ -37,12 +37,12 @@ def main():
     opaque, transparent = sc.render_objects(handles, instance_transforms=inst)
     pos, pitch, yaw = S.config5_camera() if args.instances == 16 else S.config3_camera()
     scene = S.scene_data_struct(pos, pitch, yaw, args.width, args.height)
-    r.set_option(A.OPT_KERNEL_TIMING, 1)
+    r.set_option(A.OPT_KERNEL_TIMING, 2)
     for _ in range(3):
         r.clear_color((1, 1, 1, 1))
         r.draw_geometry(scene, opaque, transparent)
     r.sync()
-    r.set_option(A.OPT_KERNEL_TIMING, 1)
+    r.set_option(A.OPT_KERNEL_TIMING, 2)
     t0 = time.perf_counter()
     for _ in range(args.frames):
         r.clear_color((1, 1, 1, 1))
@@ -59,7 +59,7 @@ def main():
         for rnd in range(8):
             for m in masks:
                 r.set_option(A.OPT_TUNING, m)
-                r.set_option(A.OPT_KERNEL_TIMING, 1 if rnd < 4 else 0)  # half the rounds without event overhead
+                r.set_option(A.OPT_KERNEL_TIMING, (2 if rnd < 2 else 1) if rnd < 4 else 0)  # all stages | tile pair | no events
                 r.sync()
                 tw = time.perf_counter()
                 for _ in range(20):
@@ -68,11 +68,13 @@ def main():
                 r.sync()
                 tw = (time.perf_counter() - tw) / 20 * 1e3
                 s2 = r.get_stats()
-                res[m].append((s2.geometry_ms, s2.binning_ms, s2.tile_ms, tw if rnd >= 4 else float("nan"), tw if rnd < 4 else float("nan")))
+                res[m].append((s2.geometry_ms, s2.binning_ms, s2.tile_ms, tw if rnd >= 4 else float("nan"),
+                               tw if 2 <= rnd < 4 else float("nan"), tw if rnd < 2 else float("nan")))
         for m in masks:
             a = np.array(res[m])
-            print(f"  tuning {m}: geometry/binning/tile median {np.nanmedian(a[:4, :3], axis=0).round(4).tolist()} ms; "
-                  f"wall ms/frame: {np.nanmedian(a[:, 3]):.4f} (no events) {np.nanmedian(a[:, 4]):.4f} (with kernel-timing events)")
+            print(f"  tuning {m}: geometry/binning/tile median {np.nanmedian(a[:2, :3], axis=0).round(4).tolist()} ms; "
+                  f"wall ms/frame: {np.nanmedian(a[:, 3]):.4f} (no events) {np.nanmedian(a[:, 4]):.4f} (tile event pair) "
+                  f"{np.nanmedian(a[:, 5]):.4f} (all stage events)")
         r.set_option(A.OPT_TUNING, 0)
     host = []
     for _ in range(10):  # GPU idle at every call: mesh_draw_time is then pure host record cost
