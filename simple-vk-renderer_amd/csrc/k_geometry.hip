@@ -29,13 +29,16 @@ __device__ __forceinline__ void shade_corner(const DrawDesc& d, uint32_t kind, c
 __global__ __launch_bounds__(256) void setup_kernel(FrameParams P) {
   uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   uint32_t lane = threadIdx.x & 63;
-  if (gw >= P.n_chunks) return;  // wave-uniform
-  WaveChunk ch = P.chunks[gw];
+  const bool live = gw < P.n_chunks;  // wave-uniform; dead waves of the last block only attend the barriers
+  WaveChunk ch = P.chunks[live ? gw : 0u];
   const DrawDesc& d = P.draws[ch.draw];
-  uint32_t tri = ch.first_tri + lane;
+  uint32_t tri = live ? ch.first_tri + lane : 0xffffffffu;
   uint32_t seq = d.tri_base + tri;
   uint32_t kind = (d.flags >> F_KIND_SHIFT) & 3u;
-  TriRec* rec = P.recs + seq;
+  __shared__ uint32_t s_tot[8];
+  __shared__ uint4 s_tr[4][64 * 8];  // per wave: one half (8 pieces) of its 64 records, for the transposed store
+  uint4 piece[16];
+  piece[0] = make_uint4(1u, 0u, 0u, 0u);  // the invalid record: minx = 1 > maxx = 0
   TriGeom g{};
   bool ok = false;  // a valid record was written and is to be binned
   if (tri < d.tri_count) {
@@ -63,11 +66,11 @@ __global__ __launch_bounds__(256) void setup_kernel(FrameParams P) {
         ScreenV s0 = to_screen(v0.clip, hw, hh), s1 = to_screen(v1.clip, hw, hh), s2 = to_screen(v2.clip, hw, hh);
         if (s0.ok && s1.ok && s2.ok) {
           to_clip = false;
-          ok = setup_triangle(P, &v0, &v1, &v2, s0, s1, s2, (seq + 1u) << 1, d.flags, P.tex[d.tex], rec, &g);
+          ok = setup_triangle(P, &v0, &v1, &v2, s0, s1, s2, (seq + 1u) << 1, d.flags, P.tex[d.tex], piece, &g);
         }
       }
     }
-    if (!ok) store_invalid(rec);
+    if (!ok) piece[0] = make_uint4(1u, 0u, 0u, 0u);
     if (ok && P.instrument) atomicAdd(&P.counters->binned, 1ull);
     if (to_clip) {  // slow path: hand over to the clipper (it links its pieces from this slot)
       uint32_t slot = atomicAdd(&P.counters->n_clip, 1u);
@@ -81,15 +84,45 @@ __global__ __launch_bounds__(256) void setup_kernel(FrameParams P) {
       }
     }
   }
+  // Store the wave's 64 consecutive records.  A lane storing its own record touches 64 different
+  // lines per instruction (256-byte stride); transposed through LDS, half a record at a time, eight
+  // lanes write one 128-byte line together.  Culled triangles only get their 16-byte header.
+  {
+    const unsigned long long act = __ballot(tri < d.tri_count), okm = __ballot(ok);
+    uint4* wave_recs = reinterpret_cast<uint4*>(P.recs + (d.tri_base + ch.first_tri));
+    uint4* sl = s_tr[threadIdx.x >> 6];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) sl[lane * 8u + ((uint32_t)i ^ (lane & 7u))] = piece[half * 8 + i];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        uint32_t t = (uint32_t)k * 8u + (lane >> 3), i = lane & 7u;
+        uint4 v = sl[t * 8u + (i ^ (t & 7u))];
+        bool header = half == 0 && i == 0u;
+        if ((act >> t) & 1ull)
+          if (header || ((okm >> t) & 1ull)) wave_recs[t * 16u + (uint32_t)half * 8u + i] = v;
+      }
+    }
+  }
   // Emit the triangle's (bin, record) pairs now, while bbox and edge functions are in registers.
   // Triangles over 16 tiles are queued instead; bin_rest (k_bin.hip) walks those wave-wide.
   TileRange tr = tile_range(P, g.minx, g.miny, g.maxx, g.maxy, ok);
-  if (ok && tr.nt > SMALL_MAX_TILES) P.big_queue[atomicAdd(&P.counters->n_big, 1u)] = seq;
+  {  // queue push, one atomic per wave
+    bool big = ok && tr.nt > SMALL_MAX_TILES;
+    unsigned long long m = __ballot(big);
+    if (m) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&P.counters->n_big, (uint32_t)__popcll(m));
+      base = __shfl(base, 0);
+      if (big) P.big_queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = seq;
+    }
+  }
   EdgeSet e;
   e.A0 = g.A[0]; e.A1 = g.A[1]; e.A2 = g.A[2]; e.B0 = g.B[0]; e.B1 = g.B[1]; e.B2 = g.B[2];
   e.C0 = g.C[0]; e.C1 = g.C[1]; e.C2 = g.C[2];
   emit_small_pairs(P, ok && tr.nt <= SMALL_MAX_TILES, tr, g.minx, g.miny, g.maxx, g.maxy,
-                   (d.flags & F_TRANSPARENT) ? P.n_tiles : 0u, e, seq);
+                   (d.flags & F_TRANSPARENT) ? P.n_tiles : 0u, e, seq, s_tot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -170,11 +203,11 @@ __global__ __launch_bounds__(64) void clip_kernel(FrameParams P) {
               s2 = to_screen(poly[i + 1].clip, hw, hh);
       if (!(s0.ok && s1.ok && s2.ok)) continue;
       if (!(poly[0].clip[3] > 0.0f && poly[i].clip[3] > 0.0f && poly[i + 1].clip[3] > 0.0f)) continue;
-      TriRec tmp;
-      if (!setup_triangle(P, &poly[0], &poly[i], &poly[i + 1], s0, s1, s2, ((seq + 1u) << 1) | 1u, d.flags, P.tex[d.tex], &tmp, nullptr)) continue;
+      uint4 piece[16];
+      if (!setup_triangle(P, &poly[0], &poly[i], &poly[i + 1], s0, s1, s2, ((seq + 1u) << 1) | 1u, d.flags, P.tex[d.tex], piece, nullptr)) continue;
       uint4* dst = reinterpret_cast<uint4*>(P.recs + P.n_tris + first + used);
-      const uint4* src = reinterpret_cast<const uint4*>(&tmp);
-      for (int k = 0; k < 16; k++) dst[k] = src[k];
+#pragma unroll
+      for (int k = 0; k < 16; k++) dst[k] = piece[k];
       used++;
       if (P.instrument) atomicAdd(&P.counters->binned, 1ull);
     }

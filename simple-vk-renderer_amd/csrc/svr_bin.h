@@ -34,23 +34,28 @@ __device__ __forceinline__ TileRange tile_range(const FrameParams& P, int minx, 
   return t;
 }
 
-// Small triangles (<= 16 tiles), called by every lane of the setup kernel's wave: each lane tests its
+// Small triangles (<= 16 tiles), called by every lane of the setup kernel's WORKGROUP (barriers inside): each lane tests its
 // own tiles (registers only), a wave prefix sum and ONE atomic reserve the wave's span of the pair
 // list, and the lanes store their (bin, record) pairs there.  Nothing here waits on memory more than
 // once, where a loop of per-tile atomics was a chain of round trips as long as the largest triangle.
 __device__ __forceinline__ void emit_small_pairs(const FrameParams& P, bool small, const TileRange& tr, int minx, int miny,
-                                                 int maxx, int maxy, uint32_t binbase, const EdgeSet& e, uint32_t rec) {
+                                                 int maxx, int maxy, uint32_t binbase, const EdgeSet& e, uint32_t rec,
+                                                 uint32_t* s_tot) {
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t mask = 0;
   if (small) {
     if (tr.nt <= 4) {
       mask = (1u << tr.nt) - 1u;
     } else {
+      int tx = tr.tx0, ty = tr.ty0;  // running tile coordinates: no integer division per tile
       for (int j = 0; j < tr.nt; j++) {
-        int ty = tr.ty0 + j / tr.ntx, tx = tr.tx0 + j % tr.ntx;
         int x0 = max(minx, (int)P.sx + tx * TILE), x1 = min(maxx, (int)P.sx + tx * TILE + TILE - 1);
         int y0 = max(miny, (int)P.sy + ty * TILE), y1 = min(maxy, (int)P.sy + ty * TILE + TILE - 1);
         if (box_overlaps(e, x0, y0, x1, y1)) mask |= 1u << j;
+        if (++tx == tr.tx0 + tr.ntx) {
+          tx = tr.tx0;
+          ty++;
+        }
       }
     }
   }
@@ -59,20 +64,36 @@ __device__ __forceinline__ void emit_small_pairs(const FrameParams& P, bool smal
     uint32_t u = __shfl_up(inc, off);
     if ((int)lane >= off) inc += u;
   }
+  // one atomic per WORKGROUP reserves the span (s_tot: 5 words of LDS handed in by the kernel): the
+  // counter is one address for the whole grid, and same-address device atomics retire one at a time
+  const uint32_t wave = threadIdx.x >> 6;
   uint32_t total = __shfl(inc, 63), base = 0;
-  if (total == 0) return;  // wave-uniform
-  if (lane == 0) base = atomicAdd(&P.counters->n_pairs, total);
-  base = __shfl(base, 0);
-  if (base + total > P.bin_cap) {  // the pass is void; the host grows the lists from n_pairs and replays
-    if (lane == 0) atomicOr(&P.counters->overflow, 4u);
+  if (lane == 63) s_tot[wave] = total;
+  __syncthreads();
+  uint32_t before = 0, block_total = 0;
+  for (uint32_t w = 0; w < 4; w++) {
+    uint32_t t = s_tot[w];
+    if (w < wave) before += t;
+    block_total += t;
+  }
+  if (block_total == 0) return;  // block-uniform
+  if (threadIdx.x == 0) s_tot[4] = atomicAdd(&P.counters->n_pairs, block_total);
+  __syncthreads();
+  base = s_tot[4];
+  if (base + block_total > P.bin_cap) {  // the pass is void; the host grows the lists from n_pairs and replays
+    if (threadIdx.x == 0) atomicOr(&P.counters->overflow, 4u);
     return;
   }
+  base += before;
   uint32_t pos = base + inc - cnt;
-  while (mask) {
-    int j = __ffs((int)mask) - 1;
-    mask &= mask - 1u;
-    uint32_t ty = (uint32_t)(tr.ty0 + j / tr.ntx), tx = (uint32_t)(tr.tx0 + j % tr.ntx);
-    P.pairs[pos++] = make_uint2(binbase + ty * P.tiles_x + tx, rec);
+  uint32_t row_bin = binbase + (uint32_t)tr.ty0 * P.tiles_x + (uint32_t)tr.tx0;
+  int tx = 0;
+  for (; mask; mask >>= 1) {
+    if (mask & 1u) P.pairs[pos++] = make_uint2(row_bin + (uint32_t)tx, rec);
+    if (++tx == tr.ntx) {
+      tx = 0;
+      row_bin += P.tiles_x;
+    }
   }
 }
 

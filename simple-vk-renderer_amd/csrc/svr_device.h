@@ -285,7 +285,7 @@ struct TriGeom {
 
 __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, const VOut* v1, const VOut* v2,
                                       ScreenV s0, ScreenV s1, ScreenV s2, uint32_t key, uint32_t draw_flags,
-                                      const TexBinding& tex, TriRec* out, TriGeom* geom) {
+                                      const TexBinding& tex, uint4 (&rec)[16], TriGeom* geom) {
   int X0 = __float2int_rn(s0.xs * 256.0f), Y0 = __float2int_rn(s0.ys * 256.0f);
   int X1 = __float2int_rn(s1.xs * 256.0f), Y1 = __float2int_rn(s1.ys * 256.0f);
   int X2 = __float2int_rn(s2.xs * 256.0f), Y2 = __float2int_rn(s2.ys * 256.0f);
@@ -334,25 +334,28 @@ __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, cons
     }
   }
 
-  uint4* q = reinterpret_cast<uint4*>(out);
+  // the record, as its sixteen 16-byte pieces (struct TriRec); the caller stores it
   uint4 h;
   h.x = ((uint32_t)(uint16_t)pminx) | ((uint32_t)(uint16_t)pminy << 16);
   h.y = ((uint32_t)(uint16_t)pmaxx) | ((uint32_t)(uint16_t)pmaxy << 16);
   h.z = key;
   h.w = flags;
-  float4 zrow = make_float4(s0.zs, s1.zs - s0.zs, s2.zs - s0.zs, inv_area);
-  reinterpret_cast<float4*>(out)[1] = zrow;
-  double2* dq = reinterpret_cast<double2*>(out);
-  dq[2] = make_double2(A[0], A[1]);
-  dq[3] = make_double2(A[2], B[0]);
-  dq[4] = make_double2(B[1], B[2]);
-  dq[5] = make_double2(C[0], C[1]);
-  out->C[2] = C[2];
-  q[0] = h;
-  out->tex_base = tex.base;
-  q[7] = make_uint4(tex.wh, tex.info, f2u(tex.min_lod), f2u(tex.max_lod));
+  rec[0] = h;
+  rec[1] = make_uint4(f2u(s0.zs), f2u(s1.zs - s0.zs), f2u(s2.zs - s0.zs), f2u(inv_area));
+  auto pack2 = [](double a, double b) {
+    unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+    return make_uint4((uint32_t)ua, (uint32_t)(ua >> 32), (uint32_t)ub, (uint32_t)(ub >> 32));
+  };
+  rec[2] = pack2(A[0], A[1]);
+  rec[3] = pack2(A[2], B[0]);
+  rec[4] = pack2(B[1], B[2]);
+  rec[5] = pack2(C[0], C[1]);
+  {
+    unsigned long long uc = (unsigned long long)__double_as_longlong(C[2]), ub = (unsigned long long)(uintptr_t)tex.base;
+    rec[6] = make_uint4((uint32_t)uc, (uint32_t)(uc >> 32), (uint32_t)ub, (uint32_t)(ub >> 32));
+  }
+  rec[7] = make_uint4(tex.wh, tex.info, f2u(tex.min_lod), f2u(tex.max_lod));
   // shading half
-  float* f = reinterpret_cast<float*>(out) + 32;
   float rw0 = s0.rw, rw1 = s1.rw, rw2 = s2.rw;
   float sh[32];
   sh[0] = rw0;
@@ -368,7 +371,7 @@ __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, cons
 #pragma unroll
   for (int k = 27; k < 32; k++) sh[k] = 0.0f;
 #pragma unroll
-  for (int k = 0; k < 8; k++) reinterpret_cast<float4*>(f)[k] = make_float4(sh[4 * k], sh[4 * k + 1], sh[4 * k + 2], sh[4 * k + 3]);
+  for (int k = 0; k < 8; k++) rec[8 + k] = make_uint4(f2u(sh[4 * k]), f2u(sh[4 * k + 1]), f2u(sh[4 * k + 2]), f2u(sh[4 * k + 3]));
   return true;
 }
 
