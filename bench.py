@@ -171,6 +171,14 @@ def main():
         frag_rank = shaded / world
         tile_bytes = 5.0 * frag_rank + 12.0 * W * slots[0].rows
         tile_s = st.tile_ms * 1e-3
+        # HBM bytes per launch of that kernel from the PMC counters cannot be collected from inside this
+        # process; the committed rocprofv3 --pmc summary of this very command (1 GPU, default size) is quoted
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_d_traffic.json")
+        if world == 1 and (W, H, args.instances, args.lod) == (3840, 2160, 1, 1) and os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic, traffic_source = tj["traffic_bytes_per_launch"], "profiles/r01_d_traffic.json: " + tj["correction"]
         achieved = tile_bytes / tile_s / 1e9 if tile_s > 0 else 0.0
         out = {
             "metric": "shaded fragments/s", "value": shaded * fps, "unit": "fragments/s",
@@ -189,7 +197,8 @@ def main():
             "binned_triangles": binned, "bin_entries": entries,
             "kernel_ms": {"tile": st.tile_ms, "passes": st.timed_passes},
             "roofline": {"bound": "hbm", "kernel": "tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": tile_bytes, "avg_launch_ms": st.tile_ms},
         }
         if not args.no_cpu_baseline:
