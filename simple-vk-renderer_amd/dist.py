@@ -46,6 +46,8 @@ class ShardedFrame:
         self.my_band = self.flat[rank * n:(rank + 1) * n]
         self.bound = bind
         self.work = None
+        self._dist = None
+        self._replays = 0  # renderer's replayed_passes as of the last finish()
 
     def begin(self):
         """Make this slot the render target; waits (on the stream) for the slot's previous gather."""
@@ -65,13 +67,30 @@ class ShardedFrame:
             self.color[self.y0:self.y0 + self.rows].copy_(t[self.y0:self.y0 + self.rows])
         if self.world == 1:
             return
+        self._dist = dist
         h = dist.all_gather_into_tensor(self.flat, self.my_band, async_op=async_op)
         self.work = h if async_op else None
 
+    def _replayed_passes(self):
+        try:
+            return int(self.r.get_stats().replayed_passes)  # fences the renderer
+        except AttributeError:  # the CPU oracle (tests) has no queues to overflow
+            return 0
+
     def finish(self):
+        """Wait for the slot's gather.  The gather is the caller's own stream work, which the renderer's
+        overflow replay (svr_api.hip, operation log) does not know about: if a pass of this frame was
+        replayed after the band had been sent, send the band again."""
         if self.work is not None:
             self.work.wait()
             self.work = None
+        if self.world > 1 and self.bound and self._dist is not None:
+            now = self._replayed_passes()  # a fence, like this whole call
+            flag = self.torch.tensor([1 if now != self._replays else 0], dtype=self.torch.int32, device=self.color.device)
+            self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX)  # the re-send is a collective: all ranks or none
+            self._replays = now
+            if int(flag.item()):
+                self._dist.all_gather_into_tensor(self.flat, self.my_band)
 
     def image(self):
         """The gathered frame without the padding rows."""
