@@ -181,6 +181,29 @@ int svr_write_material(SvrContext* ctx, int pass, const float color_factors[4],
  * current scissor (all rows unless the multi-GPU path narrowed it: a rank only owns its band). */
 int svr_clear_color(SvrContext* ctx, const float rgba[4]);
 
+/* VulkanEngine::draw_background (src/vk_engine.cpp:1341-1355): run one of the two ComputeEffects of
+ * init_background_pipelines (src/vk_engine.cpp:920-1000) over the colour target; `data` is the
+ * effect's ComputePushConstants (4 x vec4, src/vk_engine.h ComputePushConstants).
+ *   SVR_BACKGROUND_GRADIENT  shaders/gradient_color.comp:14-27: mix(data1, data2, float(y) / height)
+ *                            (engine default data1 = data2 = 1: what svr_clear_color(1,1,1,1) gives)
+ *   SVR_BACKGROUND_SKY       shaders/sky.comp: data1.xyz * y / height + star field, threshold data1.w
+ *                            (engine default data1 = (0.1, 0.2, 0.4, 0.97))
+ * Like svr_clear_color it writes the rows of the current scissor; `height` is the full target's.
+ * cos / fract / pow(.,6) of sky.comp are defined operation by operation in DESIGN.md (C15). */
+enum SvrBackground { SVR_BACKGROUND_GRADIENT = 0, SVR_BACKGROUND_SKY = 1 };
+int svr_draw_background(SvrContext* ctx, int effect, const float data[16]);
+
+/* vkutil::copy_image (src/vk_images.cpp:33-64) as VulkanEngine::draw() uses it (src/vk_engine.cpp:
+ * 1268-1280): LINEAR-filter blit of the whole colour target to a dst_width x dst_height image of the
+ * swapchain's format (B8G8R8A8_UNORM, src/vk_engine.cpp:553) — identity-sized unless the window was
+ * resized.  dst_dev: device memory, dst_width*dst_height*4 bytes, row-major (stands for the
+ * swapchain image); stream-ordered like a pass.  svr_read_swapchain does the same into an internal
+ * image and copies it to the host (tests, screenshots). */
+enum SvrSwapchainFormat { SVR_SWAPCHAIN_B8G8R8A8 = 0, SVR_SWAPCHAIN_R8G8B8A8 = 1 };
+int svr_copy_to_swapchain(SvrContext* ctx, void* dst_dev, uint32_t dst_width, uint32_t dst_height, int dst_format);
+int svr_read_swapchain(SvrContext* ctx, uint32_t dst_width, uint32_t dst_height, int dst_format, void* dst_host,
+                       size_t bytes);
+
 /* vkCmdSetScissor (src/vk_engine.cpp:1431-1437).  The reference always passes the full extent and
  * so does svr_create; the multi-GPU path gives each rank its band of rows.  The viewport stays
  * (0,0,width,height).  Pixels outside the scissor are left untouched (colour AND depth). */

@@ -946,6 +946,120 @@ int svr_clear_color(SvrContext* ctx, const float rgba[4]) {
   return SVR_OK;
 }
 
+// ---- draw_background (src/vk_engine.cpp:1341-1355): gradient_color.comp / sky.comp  (contract C14, C15)
+namespace {
+
+// cos for sky.comp's hash: three-term Cody-Waite reduction by pi/2 (fma), then the single-precision
+// minimax polynomials for sin / cos on [-pi/4, pi/4].  Every operation is spelled out: the device
+// kernel performs the same sequence, so the star field is bit-identical on both sides.
+const float kTwoOverPi = 0x1.45f306p-1f;
+const float kPio2Hi = 0x1.921fb6p+0f, kPio2Mid = -0x1.777a5cp-25f, kPio2Lo = -0x1.ee59dap-50f;
+inline float sky_cos(float x) {
+  float k = std::nearbyintf(x * kTwoOverPi);
+  float r = std::fmaf(-k, kPio2Hi, x);
+  r = std::fmaf(-k, kPio2Mid, r);
+  r = std::fmaf(-k, kPio2Lo, r);
+  float z = r * r;
+  float sn = std::fmaf(std::fmaf(std::fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  float cs = std::fmaf(std::fmaf(std::fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                       std::fmaf(-0.5f, z, 1.0f));
+  int q = (int)k & 3;  // cos(r + q*pi/2)
+  float v = (q & 1) ? sn : cs;
+  return (q == 1 || q == 2) ? -v : v;
+}
+inline float sky_fract(float a) { return a - std::floor(a); }
+inline float sky_noise2d(float x, float y) {  // shaders/sky.comp:17-22
+  float xhash = sky_cos(x * 37.0f), yhash = sky_cos(y * 57.0f);
+  return sky_fract(415.92653f * (xhash + yhash));
+}
+inline float sky_noisy_star(float x, float y, float thr) {  // shaders/sky.comp:25-33
+  float s = sky_noise2d(x, y);
+  if (!(s >= thr)) return 0.0f;
+  float t = (s - thr) / (1.0f - thr);
+  float t2 = t * t, t4 = t2 * t2;  // pow(t, 6.0)
+  return t4 * t2;
+}
+inline float sky_stable_star(float x, float y, float thr) {  // shaders/sky.comp:36-54
+  float fx = sky_fract(x), fy = sky_fract(y);
+  float gx = std::floor(x), gy = std::floor(y);
+  float v1 = sky_noisy_star(gx, gy, thr), v2 = sky_noisy_star(gx, gy + 1.0f, thr);
+  float v3 = sky_noisy_star(gx + 1.0f, gy, thr), v4 = sky_noisy_star(gx + 1.0f, gy + 1.0f, thr);
+  float acc = (v1 * (1.0f - fx)) * (1.0f - fy);
+  acc = std::fmaf(v2 * (1.0f - fx), fy, acc);
+  acc = std::fmaf(v3 * fx, 1.0f - fy, acc);
+  acc = std::fmaf(v4 * fx, fy, acc);
+  return acc;
+}
+
+}  // namespace
+
+int svr_draw_background(SvrContext* ctx, int effect, const float data[16]) {
+  if (!ctx || !data) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_background: null argument");
+  if (effect != SVR_BACKGROUND_GRADIENT && effect != SVR_BACKGROUND_SKY)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_background: unknown effect");
+  const float fh = (float)ctx->H;
+  for (uint32_t y = ctx->sy; y < ctx->sy + ctx->sh; y++)
+    for (uint32_t x = 0; x < ctx->W; x++) {
+      float out[4];
+      if (effect == SVR_BACKGROUND_GRADIENT) {  // shaders/gradient_color.comp:19-26
+        float blend = (float)y / fh;
+        for (int c = 0; c < 4; c++) out[c] = std::fmaf(data[4 + c], blend, data[c] * (1.0f - blend));
+      } else {  // shaders/sky.comp:56-76 (fragCoord = the integer texel coordinate)
+        float fx = (float)x, fy = (float)y;
+        float star = sky_stable_star(fx + 0.2f, fy + -0.06f, data[3]);
+        for (int c = 0; c < 3; c++) out[c] = (data[c] * fy) / fh + star;
+        out[3] = 1.0f;
+      }
+      store_color(ctx, (size_t)y * ctx->W + x, out);
+    }
+  return SVR_OK;
+}
+
+// ---- vkutil::copy_image (src/vk_images.cpp:33-64): LINEAR blit to the swapchain format  (contract C16)
+static int blit_to(SvrContext* ctx, uint32_t dw, uint32_t dh, int fmt, uint8_t* dst) {
+  const float su = (float)ctx->W / (float)dw, sv = (float)ctx->H / (float)dh;
+  for (uint32_t j = 0; j < dh; j++)
+    for (uint32_t i = 0; i < dw; i++) {
+      float u = ((float)i + 0.5f) * su - 0.5f, v = ((float)j + 0.5f) * sv - 0.5f;
+      float fu = std::floor(u), fv = std::floor(v);
+      float a = u - fu, b = v - fv;
+      long i0 = (long)fu, j0 = (long)fv, i1 = i0 + 1, j1 = j0 + 1;
+      auto clampi = [](long t, long hi) { return t < 0 ? 0 : (t > hi ? hi : t); };
+      i0 = clampi(i0, (long)ctx->W - 1); i1 = clampi(i1, (long)ctx->W - 1);
+      j0 = clampi(j0, (long)ctx->H - 1); j1 = clampi(j1, (long)ctx->H - 1);
+      float t00[4], t10[4], t01[4], t11[4], o[4];
+      load_color(ctx, (size_t)j0 * ctx->W + i0, t00);
+      load_color(ctx, (size_t)j0 * ctx->W + i1, t10);
+      load_color(ctx, (size_t)j1 * ctx->W + i0, t01);
+      load_color(ctx, (size_t)j1 * ctx->W + i1, t11);
+      for (int c = 0; c < 4; c++) {
+        float top = std::fmaf(a, t10[c] - t00[c], t00[c]), bot = std::fmaf(a, t11[c] - t01[c], t01[c]);
+        o[c] = std::fmaf(b, bot - top, top);
+      }
+      uint8_t* d = dst + ((size_t)j * dw + i) * 4;
+      if (fmt == SVR_SWAPCHAIN_B8G8R8A8) {
+        d[0] = f32_to_unorm8(o[2]); d[1] = f32_to_unorm8(o[1]); d[2] = f32_to_unorm8(o[0]); d[3] = f32_to_unorm8(o[3]);
+      } else {
+        for (int c = 0; c < 4; c++) d[c] = f32_to_unorm8(o[c]);
+      }
+    }
+  return SVR_OK;
+}
+
+int svr_read_swapchain(SvrContext* ctx, uint32_t dw, uint32_t dh, int fmt, void* dst, size_t bytes) {
+  if (!ctx || !dst) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_read_swapchain: null argument");
+  if (dw == 0 || dh == 0 || dw > 16384 || dh > 16384) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_read_swapchain: extent must be in 1..16384");
+  if (fmt != SVR_SWAPCHAIN_B8G8R8A8 && fmt != SVR_SWAPCHAIN_R8G8B8A8)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_read_swapchain: unknown format");
+  if (bytes < (size_t)dw * dh * 4) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_read_swapchain: buffer too small");
+  return blit_to(ctx, dw, dh, fmt, (uint8_t*)dst);
+}
+
+// the oracle has no device memory: the "swapchain image" is host memory here
+int svr_copy_to_swapchain(SvrContext* ctx, void* dst, uint32_t dw, uint32_t dh, int fmt) {
+  return svr_read_swapchain(ctx, dw, dh, fmt, dst, (size_t)dw * dh * 4);
+}
+
 int svr_set_scissor(SvrContext* ctx, uint32_t x, uint32_t y, uint32_t w, uint32_t h) {
   if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
   if (w == 0 || h == 0 || (uint64_t)x + w > ctx->W || (uint64_t)y + h > ctx->H)

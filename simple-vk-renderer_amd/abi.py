@@ -70,11 +70,16 @@ OPT_KERNEL_TIMING = 2
 OPT_TILE_CYCLES = 3
 OPT_TUNING = 4
 OPT_QUEUE_CAPS = 5
+BACKGROUND_GRADIENT, BACKGROUND_SKY = 0, 1
+SWAPCHAIN_B8G8R8A8, SWAPCHAIN_R8G8B8A8 = 0, 1
+GRADIENT_DEFAULT = (1.0, 1.0, 1.0, 1.0) * 2 + (0.0,) * 8       # src/vk_engine.cpp:981-982
+SKY_DEFAULT = (0.1, 0.2, 0.4, 0.97) + (0.0,) * 12               # src/vk_engine.cpp:988
 
 # every symbol include/svr.h declares
 SYMBOLS = ["svr_create", "svr_destroy", "svr_set_stream", "svr_bind_targets", "svr_get_targets",
            "svr_upload_mesh", "svr_destroy_mesh", "svr_create_image", "svr_destroy_image",
            "svr_read_image_level", "svr_create_sampler", "svr_write_material", "svr_clear_color",
+           "svr_draw_background", "svr_copy_to_swapchain", "svr_read_swapchain",
            "svr_set_scissor", "svr_draw_geometry", "svr_draw_colored_triangle", "svr_draw_tex_image",
            "svr_run_mesh_vert", "svr_set_option", "svr_debug_trace_pixel", "svr_debug_read_trace", "svr_debug_read_bins", "svr_debug_read_tile_cycles", "svr_sync", "svr_read_color", "svr_read_depth", "svr_get_stats",
            "svr_last_error", "svr_backend_name"]
@@ -114,6 +119,9 @@ class SvrLib:
         L.svr_write_material.argtypes = [P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                          C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
         L.svr_clear_color.argtypes = [P, C.POINTER(C.c_float)]
+        L.svr_draw_background.argtypes = [P, C.c_int, C.POINTER(C.c_float)]
+        L.svr_copy_to_swapchain.argtypes = [P, P, C.c_uint32, C.c_uint32, C.c_int]
+        L.svr_read_swapchain.argtypes = [P, C.c_uint32, C.c_uint32, C.c_int, P, C.c_size_t]
         L.svr_set_scissor.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.svr_draw_geometry.argtypes = [P, C.POINTER(SvrSceneData), P, C.c_size_t, P, C.c_size_t,
                                         C.POINTER(SvrStats)]
@@ -244,6 +252,19 @@ class Renderer:
 
     def clear_color(self, rgba=(1.0, 1.0, 1.0, 1.0)):
         self.lib.check(self.lib.lib.svr_clear_color(self.h, _f4(rgba)))
+
+    def draw_background(self, effect, data):
+        """effect: BACKGROUND_GRADIENT / BACKGROUND_SKY; data: the 16 floats of ComputePushConstants."""
+        arr = (C.c_float * 16)(*[float(v) for v in data])
+        self.lib.check(self.lib.lib.svr_draw_background(self.h, int(effect), arr))
+
+    def copy_to_swapchain(self, dst_ptr, width, height, fmt=0):
+        self.lib.check(self.lib.lib.svr_copy_to_swapchain(self.h, C.c_void_p(dst_ptr), width, height, fmt))
+
+    def read_swapchain(self, width, height, fmt=0):
+        out = np.empty((height, width, 4), dtype=np.uint8)
+        self.lib.check(self.lib.lib.svr_read_swapchain(self.h, width, height, fmt, out.ctypes.data, out.nbytes))
+        return out
 
     def set_scissor(self, x, y, w, h):
         self.lib.check(self.lib.lib.svr_set_scissor(self.h, x, y, w, h))

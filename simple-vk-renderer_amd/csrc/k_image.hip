@@ -4,7 +4,9 @@
 //   downsample      one level of vkutil::generate_mipmaps (src/vk_images.cpp:95-128): 2:1 LINEAR blit
 //                   in exact integer arithmetic (contract C13)
 //   rgba16f_to_rgba8  identity-extent vkutil::copy_image (src/vk_images.cpp:33-64): clamp, *255, RNE
-// All three are pure streaming kernels: 16 bytes per lane, grid-stride, HBM-bound.
+//   background      draw_background's two compute effects (gradient_color.comp, sky.comp)
+//   blit            vkutil::copy_image in general: LINEAR-filter scaling blit to the swapchain format
+// All are pure streaming kernels, grid-stride, HBM-bound.
 #include <hip/hip_fp16.h>
 
 #include "svr_launch.h"
@@ -95,6 +97,138 @@ __global__ __launch_bounds__(256) void cvt16f_to_8_kernel(const uint2* src, uint
     dst[i] = h2un8(p.x & 0xffffu) | (h2un8(p.x >> 16) << 8) | (h2un8(p.y & 0xffffu) << 16) | (h2un8(p.y >> 16) << 24);
   }
 }
+// ------------------------------------------------------------------------------------------------
+// draw_background (src/vk_engine.cpp:1341-1355): gradient_color.comp and sky.comp  (contract C14, C15).
+// One lane per pixel of the scissor's rows, 8 (RGBA16F) or 4 (RGBA8) bytes written per lane.
+__device__ __forceinline__ float pin32(float x) {  // keep "fp32 result, then the store's rounding" apart (see Codec)
+  asm volatile("" : "+v"(x));
+  return x;
+}
+__device__ __forceinline__ void store_target(void* color, int fmt, size_t p, float r, float g, float b, float a) {
+  if (fmt == SVR_COLOR_RGBA16F) {
+    r = pin32(r); g = pin32(g); b = pin32(b); a = pin32(a);
+    uint32_t hr = __half_as_ushort(__float2half_rn(r)), hg = __half_as_ushort(__float2half_rn(g));
+    uint32_t hb = __half_as_ushort(__float2half_rn(b)), ha = __half_as_ushort(__float2half_rn(a));
+    reinterpret_cast<uint2*>(color)[p] = make_uint2(hr | (hg << 16), hb | (ha << 16));
+  } else {
+    auto un8 = [](float f) { return (uint32_t)__float2int_rn(fminf(fmaxf(f, 0.0f), 1.0f) * 255.0f); };
+    reinterpret_cast<uint32_t*>(color)[p] = un8(r) | (un8(g) << 8) | (un8(b) << 16) | (un8(a) << 24);
+  }
+}
+
+// cos for sky.comp's hash, operation by operation as the oracle's sky_cos (three-term Cody-Waite by
+// pi/2 with fma, minimax sin/cos on the reduced argument)
+__device__ __forceinline__ float sky_cos(float x) {
+  const float kTwoOverPi = 0x1.45f306p-1f, kPio2Hi = 0x1.921fb6p+0f, kPio2Mid = -0x1.777a5cp-25f, kPio2Lo = -0x1.ee59dap-50f;
+  float k = rintf(x * kTwoOverPi);
+  float r = fmaf(-k, kPio2Hi, x);
+  r = fmaf(-k, kPio2Mid, r);
+  r = fmaf(-k, kPio2Lo, r);
+  float z = r * r;
+  float sn = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  float cs = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                  fmaf(-0.5f, z, 1.0f));
+  int q = (int)k & 3;
+  float v = (q & 1) ? sn : cs;
+  return (q == 1 || q == 2) ? -v : v;
+}
+__device__ __forceinline__ float sky_fract(float a) { return a - floorf(a); }
+__device__ __forceinline__ float sky_noisy_star(float x, float y, float thr) {
+  float s = sky_fract(415.92653f * (sky_cos(x * 37.0f) + sky_cos(y * 57.0f)));
+  if (!(s >= thr)) return 0.0f;
+  float t = (s - thr) / (1.0f - thr);
+  float t2 = t * t, t4 = t2 * t2;
+  return t4 * t2;
+}
+
+struct BackgroundData {
+  float d[16];
+};
+__global__ __launch_bounds__(256) void background_kernel(void* color, int fmt, uint32_t W, uint32_t H, uint32_t y_first,
+                                                         uint32_t n_rows, int effect, BackgroundData pc, const uint32_t* poison) {
+  if (*poison) return;
+  const float fh = (float)H;
+  const uint32_t n = W * n_rows;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    uint32_t x = i % W, y = y_first + i / W;
+    float r, g, b, a;
+    if (effect == SVR_BACKGROUND_GRADIENT) {
+      float blend = (float)y / fh, inv = 1.0f - blend;
+      r = fmaf(pc.d[4], blend, pc.d[0] * inv);
+      g = fmaf(pc.d[5], blend, pc.d[1] * inv);
+      b = fmaf(pc.d[6], blend, pc.d[2] * inv);
+      a = fmaf(pc.d[7], blend, pc.d[3] * inv);
+    } else {
+      float fx = (float)x, fy = (float)y, thr = pc.d[3];
+      float sx = fx + 0.2f, sy = fy + -0.06f;
+      float frx = sky_fract(sx), fry = sky_fract(sy), gx = floorf(sx), gy = floorf(sy);
+      float v1 = sky_noisy_star(gx, gy, thr), v2 = sky_noisy_star(gx, gy + 1.0f, thr);
+      float v3 = sky_noisy_star(gx + 1.0f, gy, thr), v4 = sky_noisy_star(gx + 1.0f, gy + 1.0f, thr);
+      float star = (v1 * (1.0f - frx)) * (1.0f - fry);
+      star = fmaf(v2 * (1.0f - frx), fry, star);
+      star = fmaf(v3 * frx, 1.0f - fry, star);
+      star = fmaf(v4 * frx, fry, star);
+      r = (pc.d[0] * fy) / fh + star;
+      g = (pc.d[1] * fy) / fh + star;
+      b = (pc.d[2] * fy) / fh + star;
+      a = 1.0f;
+    }
+    store_target(color, fmt, (size_t)y * W + x, r, g, b, a);
+  }
+}
+void launch_background(void* color, int color_format, uint32_t W, uint32_t H, uint32_t y_first, uint32_t n_rows, int effect,
+                       const float data[16], const uint32_t* poison, hipStream_t s) {
+  BackgroundData pc;
+  for (int i = 0; i < 16; i++) pc.d[i] = data[i];
+  hipLaunchKernelGGL(background_kernel, dim3(stream_grid(W * n_rows)), dim3(256), 0, s, color, color_format, W, H, y_first, n_rows,
+                     effect, pc, poison);
+}
+
+// ------------------------------------------------------------------------------------------------
+// vkutil::copy_image (src/vk_images.cpp:33-64): LINEAR blit of the colour target to the swapchain's
+// format and extent (contract C16).  One lane per destination pixel; identity extent degenerates to
+// weights 0 and is exactly the plain format conversion.
+__device__ __forceinline__ float4 load_target(const void* color, int fmt, size_t p) {
+  if (fmt == SVR_COLOR_RGBA16F) {
+    uint2 e = reinterpret_cast<const uint2*>(color)[p];
+    return make_float4(__half2float(__ushort_as_half((unsigned short)(e.x & 0xffffu))), __half2float(__ushort_as_half((unsigned short)(e.x >> 16))),
+                       __half2float(__ushort_as_half((unsigned short)(e.y & 0xffffu))), __half2float(__ushort_as_half((unsigned short)(e.y >> 16))));
+  }
+  uint32_t t = reinterpret_cast<const uint32_t*>(color)[p];
+  const float k = 0x1.010102p-8f;
+  return make_float4((float)(t & 0xffu) * k, (float)((t >> 8) & 0xffu) * k, (float)((t >> 16) & 0xffu) * k, (float)(t >> 24) * k);
+}
+__global__ __launch_bounds__(256) void blit_kernel(const void* color, int fmt, uint32_t W, uint32_t H, uint32_t* dst, uint32_t dw,
+                                                   uint32_t dh, int dst_format, const uint32_t* poison) {
+  if (*poison) return;
+  const float su = (float)W / (float)dw, sv = (float)H / (float)dh;
+  const uint32_t n = dw * dh;
+  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    uint32_t i = idx % dw, j = idx / dw;
+    float u = ((float)i + 0.5f) * su - 0.5f, v = ((float)j + 0.5f) * sv - 0.5f;
+    float fu = floorf(u), fv = floorf(v);
+    float a = u - fu, b = v - fv;
+    int i0 = (int)fu, j0 = (int)fv, i1 = i0 + 1, j1 = j0 + 1;
+    i0 = min(max(i0, 0), (int)W - 1); i1 = min(max(i1, 0), (int)W - 1);
+    j0 = min(max(j0, 0), (int)H - 1); j1 = min(max(j1, 0), (int)H - 1);
+    float4 t00 = load_target(color, fmt, (size_t)j0 * W + i0), t10 = load_target(color, fmt, (size_t)j0 * W + i1);
+    float4 t01 = load_target(color, fmt, (size_t)j1 * W + i0), t11 = load_target(color, fmt, (size_t)j1 * W + i1);
+    auto filt = [&](float c00, float c10, float c01, float c11) {
+      float top = fmaf(a, c10 - c00, c00), bot = fmaf(a, c11 - c01, c01);
+      return fmaf(b, bot - top, top);
+    };
+    auto un8 = [](float f) { return (uint32_t)__float2int_rn(fminf(fmaxf(f, 0.0f), 1.0f) * 255.0f); };
+    uint32_t r = un8(filt(t00.x, t10.x, t01.x, t11.x)), g = un8(filt(t00.y, t10.y, t01.y, t11.y));
+    uint32_t bl = un8(filt(t00.z, t10.z, t01.z, t11.z)), al = un8(filt(t00.w, t10.w, t01.w, t11.w));
+    dst[idx] = dst_format == SVR_SWAPCHAIN_B8G8R8A8 ? (bl | (g << 8) | (r << 16) | (al << 24)) : (r | (g << 8) | (bl << 16) | (al << 24));
+  }
+}
+void launch_blit(const void* color, int color_format, uint32_t W, uint32_t H, void* dst, uint32_t dw, uint32_t dh, int dst_format,
+                 const uint32_t* poison, hipStream_t s) {
+  hipLaunchKernelGGL(blit_kernel, dim3(stream_grid(dw * dh)), dim3(256), 0, s, color, color_format, W, H, (uint32_t*)dst, dw, dh,
+                     dst_format, poison);
+}
+
 void launch_rgba16f_to_rgba8(const void* src, void* dst, uint32_t n_pixels, hipStream_t s) {
   hipLaunchKernelGGL(cvt16f_to_8_kernel, dim3(stream_grid(n_pixels)), dim3(256), 0, s, (const uint2*)src,
                      (uint32_t*)dst, n_pixels);

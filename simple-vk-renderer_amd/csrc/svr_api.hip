@@ -134,10 +134,18 @@ struct SvrContext {
     bool is_pass = false;
     uint32_t seq = 0;  // passes: running number, reported by the device if the pass overflows
     int slot = 0;  // index into h_counters / op_done
+    int fill_kind = 0;  // not a pass: 0 clear, 1 background effect, 2 blit to the swapchain image
     void* clear_rows = nullptr;  // clear: first row, pixel count, format, encoded texel
     uint32_t clear_pixels = 0;
     int clear_fmt = 0;
     uint64_t clear_packed = 0;
+    void* target = nullptr;  // background / blit: colour target, its extent, the scissor's rows
+    uint32_t tw = 0, th = 0, y_first = 0, n_rows = 0;
+    int bg_effect = 0;
+    float bg_data[16] = {};
+    void* blit_dst = nullptr;
+    uint32_t blit_w = 0, blit_h = 0;
+    int blit_fmt = 0;
     FrameParams P{};  // pass: parameters as recorded + its draw list
     std::vector<DrawDesc> draws;
   };
@@ -428,8 +436,13 @@ void note_pass_stats(SvrContext* ctx, const FrameParams&, const Counters& c) {  
 int log_slot(SvrContext* ctx, int* slot);
 int retire_ops(SvrContext* ctx, bool blocking);
 
-int submit_clear(SvrContext* ctx, const SvrContext::LoggedOp& op) {
-  launch_fill_color(op.clear_rows, op.clear_pixels, op.clear_fmt, op.clear_packed, ctx->d_poison, ctx->stream);
+int submit_clear(SvrContext* ctx, const SvrContext::LoggedOp& op) {  // every logged operation that is not a pass
+  if (op.fill_kind == 0)
+    launch_fill_color(op.clear_rows, op.clear_pixels, op.clear_fmt, op.clear_packed, ctx->d_poison, ctx->stream);
+  else if (op.fill_kind == 1)
+    launch_background(op.target, op.clear_fmt, op.tw, op.th, op.y_first, op.n_rows, op.bg_effect, op.bg_data, ctx->d_poison, ctx->stream);
+  else
+    launch_blit(op.target, op.clear_fmt, op.tw, op.th, op.blit_dst, op.blit_w, op.blit_h, op.blit_fmt, ctx->d_poison, ctx->stream);
   HIPCHK(hipGetLastError());
   return SVR_OK;
 }
@@ -892,6 +905,70 @@ int svr_clear_color(SvrContext* ctx, const float rgba[4]) {
   op.clear_fmt = ctx->fmt;
   op.clear_packed = packed;
   return submit_clear(ctx, op);
+}
+
+int svr_draw_background(SvrContext* ctx, int effect, const float data[16]) {
+  if (!ctx || !data) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_background: null argument");
+  if (effect != SVR_BACKGROUND_GRADIENT && effect != SVR_BACKGROUND_SKY)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_background: unknown effect");
+  if (int e = use_device(ctx)) return e;
+  if (int e = poll_pending(ctx)) return e;
+  int slot = 0;
+  if (int e = log_slot(ctx, &slot)) return e;
+  ctx->log.emplace_back();
+  SvrContext::LoggedOp& op = ctx->log.back();
+  op.slot = slot;
+  op.fill_kind = 1;
+  op.target = ctx->color;
+  op.clear_fmt = ctx->fmt;
+  op.tw = ctx->W;
+  op.th = ctx->H;
+  op.y_first = ctx->sy;
+  op.n_rows = ctx->sh;
+  op.bg_effect = effect;
+  std::memcpy(op.bg_data, data, sizeof(op.bg_data));
+  return submit_clear(ctx, op);
+}
+
+static int blit_checks(SvrContext* ctx, const void* dst, uint32_t dw, uint32_t dh, int fmt, const char* who) {
+  if (!ctx || !dst) return fail(SVR_ERR_INVALID_ARGUMENT, std::string(who) + ": null argument");
+  if (dw == 0 || dh == 0 || dw > 16384 || dh > 16384) return fail(SVR_ERR_INVALID_ARGUMENT, std::string(who) + ": extent must be in 1..16384");
+  if (fmt != SVR_SWAPCHAIN_B8G8R8A8 && fmt != SVR_SWAPCHAIN_R8G8B8A8) return fail(SVR_ERR_INVALID_ARGUMENT, std::string(who) + ": unknown format");
+  return SVR_OK;
+}
+
+int svr_copy_to_swapchain(SvrContext* ctx, void* dst_dev, uint32_t dw, uint32_t dh, int fmt) {
+  if (int e = blit_checks(ctx, dst_dev, dw, dh, fmt, "svr_copy_to_swapchain")) return e;
+  if (int e = use_device(ctx)) return e;
+  if (int e = poll_pending(ctx)) return e;
+  int slot = 0;
+  if (int e = log_slot(ctx, &slot)) return e;
+  ctx->log.emplace_back();
+  SvrContext::LoggedOp& op = ctx->log.back();
+  op.slot = slot;
+  op.fill_kind = 2;
+  op.target = ctx->color;
+  op.clear_fmt = ctx->fmt;
+  op.tw = ctx->W;
+  op.th = ctx->H;
+  op.blit_dst = dst_dev;
+  op.blit_w = dw;
+  op.blit_h = dh;
+  op.blit_fmt = fmt;
+  return submit_clear(ctx, op);
+}
+
+int svr_read_swapchain(SvrContext* ctx, uint32_t dw, uint32_t dh, int fmt, void* dst_host, size_t bytes) {
+  if (int e = blit_checks(ctx, dst_host, dw, dh, fmt, "svr_read_swapchain")) return e;
+  if (bytes < (size_t)dw * dh * 4) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_read_swapchain: buffer too small");
+  if (int e = use_device(ctx)) return e;
+  if (int e = finish_pending(ctx)) return e;  // the read-back is a fence
+  if (int e = ctx->d_cvt.ensure((size_t)dw * dh * 4)) return e;
+  launch_blit(ctx->color, ctx->fmt, ctx->W, ctx->H, ctx->d_cvt.p, dw, dh, fmt, ctx->d_poison, ctx->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(dst_host, ctx->d_cvt.p, (size_t)dw * dh * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return SVR_OK;
 }
 
 int svr_set_scissor(SvrContext* ctx, uint32_t x, uint32_t y, uint32_t w, uint32_t h) {

@@ -347,3 +347,75 @@ def test_rgba8_target(oracle):
     # opaque-only pixels: RGBA8 target == fp16 target read back as RGBA8 up to the double rounding (1 LSB)
     d = np.abs(a["rgba8"].astype(int) - b["rgba8"].astype(int))
     assert np.percentile(d, 99) <= 1
+
+
+# ---------------------------------------------------------------- a23 / §8f-2: draw_background, copy_image
+def test_background_gradient_values(oracle):
+    """gradient_color.comp: mix(data1, data2, float(y)/height); the engine default (both white) is the
+    clear; a red->blue gradient has analytic rows."""
+    r = oracle.create(8, 4)
+    r.draw_background(A.BACKGROUND_GRADIENT, A.GRADIENT_DEFAULT)
+    assert np.all(r.read_color(as_rgba8=True) == 255)
+    data = (1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1.0, 1.0) + (0.0,) * 8
+    r.draw_background(A.BACKGROUND_GRADIENT, data)
+    c = T.f16_bits_to_f32(r.read_color())
+    for y in range(4):
+        blend = np.float32(y) / np.float32(4)
+        assert np.all(c[y, :, 0] == np.float16(np.float32(1) - blend)) and np.all(c[y, :, 2] == np.float16(blend))
+        assert np.all(c[y, :, 1] == 0) and np.all(c[y, :, 3] == 1)
+    r.close()
+
+
+def test_background_respects_the_scissor_rows(oracle):
+    r = oracle.create(16, 16)
+    r.clear_color((0.0, 0.0, 0.0, 1.0))
+    r.set_scissor(0, 4, 16, 8)
+    r.draw_background(A.BACKGROUND_GRADIENT, A.GRADIENT_DEFAULT)
+    c = r.read_color(as_rgba8=True)
+    assert np.all(c[4:12, :, :3] == 255) and np.all(c[:4, :, :3] == 0) and np.all(c[12:, :, :3] == 0)
+    r.close()
+
+
+def test_background_sky_properties(oracle):
+    """sky.comp: colour = data1.xyz * y / height + stars, alpha 1; stars are sparse at threshold 0.97 and
+    the field does not depend on how the frame is cut into scissor bands."""
+    W, H = 96, 64
+    r = oracle.create(W, H)
+    r.draw_background(A.BACKGROUND_SKY, A.SKY_DEFAULT)
+    full = T.f16_bits_to_f32(r.read_color())
+    assert np.all(full[..., 3] == 1.0)
+    base = (np.float32(0.4) * np.arange(H, dtype=np.float32)) / np.float32(H)
+    star = full[..., 2] - base[:, None].astype(np.float16).astype(np.float32)
+    assert (star > 0.01).mean() < 0.1 and (star > 0.01).sum() > 0       # sparse, but there
+    assert np.all(full[..., 2] >= base[:, None].astype(np.float16).astype(np.float32) - 1e-3)
+    r.clear_color((0, 0, 0, 0))
+    for y0 in range(0, H, 16):
+        r.set_scissor(0, y0, W, 16)
+        r.draw_background(A.BACKGROUND_SKY, A.SKY_DEFAULT)
+    assert np.array_equal(T.f16_bits_to_f32(r.read_color()), full)
+    r.close()
+
+
+def test_swapchain_blit(oracle):
+    """copy_image: identity extent = the plain format conversion (and B8G8R8A8 is its channel swap);
+    a 2:1 reduction of a 2x2 checker averages to the midpoint; magnification interpolates."""
+    out = T.render_config1(oracle, 64)
+    r = oracle.create(64, 64)
+    r.clear_color((1, 1, 1, 1))
+    r.draw_colored_triangle()
+    rgba = r.read_swapchain(64, 64, A.SWAPCHAIN_R8G8B8A8)
+    bgra = r.read_swapchain(64, 64, A.SWAPCHAIN_B8G8R8A8)
+    assert np.array_equal(rgba, out["rgba8"])
+    assert np.array_equal(bgra[..., [2, 1, 0, 3]], rgba)
+    r.close()
+    r = oracle.create(4, 4)
+    for y in range(4):     # rows alternate black / white through one-row scissors
+        r.set_scissor(0, y, 4, 1)
+        r.clear_color((1, 1, 1, 1) if y & 1 else (0, 0, 0, 1))
+    half = r.read_swapchain(4, 2, A.SWAPCHAIN_R8G8B8A8)
+    assert np.all(half[..., :3] == 128) and np.all(half[..., 3] == 255)   # 0.5 * 255 = 127.5 -> RNE 128
+    up = r.read_swapchain(4, 8, A.SWAPCHAIN_R8G8B8A8)[:, 0, 0].astype(int)
+    assert up[0] == 0 and up[-1] == 255 and np.all(np.diff(up[:3]) >= 0)
+    with pytest.raises(A.SvrError):
+        r.read_swapchain(0, 4)
+    r.close()

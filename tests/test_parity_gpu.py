@@ -106,6 +106,61 @@ def test_overflow_inside_an_unfenced_sequence(hip, oracle):
     assert a["stats"].replayed_passes == 0
 
 
+def _background_and_blit(lib, w, h, fmt, effect, data, blits):
+    r = lib.create(w, h, fmt)
+    r.clear_color((0.2, 0.4, 0.6, 1.0))
+    r.set_scissor(0, 3, w, h - 7)
+    r.draw_background(effect, data)
+    r.set_scissor(0, 0, w, h)
+    r.draw_colored_triangle()
+    out = {"color": r.read_color()}
+    for k, (dw, dh, f) in enumerate(blits):
+        out[f"blit{k}"] = r.read_swapchain(dw, dh, f)
+    r.close()
+    return out
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("effect", ["gradient", "sky"])
+def test_background_and_swapchain_blit(hip, oracle, fmt, effect):
+    """draw_background's two effects and the scaling copy_image, bit for bit (odd sizes, both target
+    formats, both swapchain channel orders, minification and magnification)."""
+    data = (0.9, 0.1, 0.3, 1.0, 0.05, 0.6, 1.7, 0.5) + (0.0,) * 8 if effect == "gradient" else A.SKY_DEFAULT
+    eff = A.BACKGROUND_GRADIENT if effect == "gradient" else A.BACKGROUND_SKY
+    blits = [(333, 187, 0), (333, 187, 1), (160, 90, 0), (500, 401, 1), (1, 1, 0), (1024, 7, 0)]
+    a, b = both(_background_and_blit, hip, oracle, 333, 187, fmt, eff, data, blits)
+    for k in a:
+        T.assert_images_identical(a[k], b[k], f"{effect} fmt {fmt} {k}")
+
+
+def test_sky_at_4k_matches_the_oracle_rows(hip, oracle):
+    """The star hash amplifies any difference in cos(): compare a band of rows at the far end of a
+    3840x2160 target (largest arguments) against the oracle."""
+    outs = []
+    for lib in (hip, oracle):
+        r = lib.create(3840, 2160)
+        r.set_scissor(0, 2100, 3840, 60)
+        r.draw_background(A.BACKGROUND_SKY, A.SKY_DEFAULT)
+        outs.append(r.read_color()[2100:])
+        r.close()
+    T.assert_images_identical(outs[0], outs[1], "sky rows 2100..2159 at 4K")
+
+
+def test_copy_to_swapchain_device_image(hip):
+    """svr_copy_to_swapchain writes caller-owned device memory in stream order."""
+    import torch
+    r = hip.create(256, 256)
+    r.clear_color((1, 1, 1, 1))
+    r.draw_colored_triangle()
+    dst = torch.zeros((128, 128, 4), dtype=torch.uint8, device="cuda")
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    r.copy_to_swapchain(dst.data_ptr(), 128, 128, A.SWAPCHAIN_B8G8R8A8)
+    r.sync()
+    torch.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy(), r.read_swapchain(128, 128, A.SWAPCHAIN_B8G8R8A8))
+    r.close()
+
+
 def test_rgba8_target(hip, oracle):
     a, b = both(T.render_sponza, hip, oracle, 320, 180, lod=8, tex_size=64, color_format=A.COLOR_RGBA8, instrument=True)
     assert_same(a, b, "config3 rgba8")
