@@ -13,6 +13,7 @@
 #include <string>
 
 #include "svr_engine.h"
+#include "svr_png.h"
 
 using namespace svrhost;
 
@@ -47,19 +48,40 @@ static void dump(const std::string& path, const T* p, size_t n) {
 }
 
 int main(int argc, char** argv) {
-  std::string lib, prefix;
+  std::string lib, prefix, gltf, png;
   uint32_t w = 160, h = 90;
-  int frames = 2;
+  int frames = 2, background = 0;
+  float cam[5] = {0, 0, 0, 0, 0};  // position, pitch, yaw
+  uint32_t sw = 0, sh = 0;
   for (int i = 1; i + 1 < argc; i += 2) {
     std::string a = argv[i];
     if (a == "--lib") lib = argv[i + 1];
+    else if (a == "--gltf") gltf = argv[i + 1];
+    else if (a == "--png") png = argv[i + 1];
+    else if (a == "--background") background = atoi(argv[i + 1]);
+    else if (a == "--swapchain" && sscanf(argv[i + 1], "%ux%u", &sw, &sh) == 2) {}
+    else if (a == "--camera" && sscanf(argv[i + 1], "%f,%f,%f,%f,%f", &cam[0], &cam[1], &cam[2], &cam[3], &cam[4]) == 5) {}
     else if (a == "--width") w = (uint32_t)atoi(argv[i + 1]);
     else if (a == "--height") h = (uint32_t)atoi(argv[i + 1]);
     else if (a == "--frames") frames = atoi(argv[i + 1]);
     else if (a == "--dump") prefix = argv[i + 1];
   }
+  if (!png.empty()) {  // decoder check: PNG file -> <prefix>.rgba (tests/test_gltf_loader.py)
+    std::ifstream f(png, std::ios::binary);
+    std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    svrpng::Image img;
+    std::string err;
+    if (!svrpng::decode(bytes.data(), bytes.size(), img, &err)) {
+      fprintf(stderr, "png: %s\n", err.c_str());
+      return 1;
+    }
+    printf("png %u %u\n", img.w, img.h);
+    if (!prefix.empty()) dump(prefix + ".rgba", img.rgba.data(), img.rgba.size());
+    return 0;
+  }
   if (lib.empty()) {
-    fprintf(stderr, "usage: svr_demo --lib <shared library exporting svr.h> [--width W --height H --frames N --dump prefix]\n");
+    fprintf(stderr, "usage: svr_demo --lib <shared library exporting svr.h> [--width W --height H --frames N --dump prefix]\n"
+                    "                [--gltf file.glb|file.gltf --camera x,y,z,pitch,yaw] [--background 0|1] [--swapchain WxH]\n");
     return 2;
   }
   SvrEngine eng;
@@ -69,6 +91,25 @@ int main(int argc, char** argv) {
   }
   printf("backend %s, %ux%u\n", eng.api.svr_backend_name(), w, h);
 
+  eng.current_background_effect = background;
+  eng.swapchain_width = sw;
+  eng.swapchain_height = sh;
+  if (!gltf.empty()) {  // VulkanEngine::init: load_gltf_meshes(this, path) -> loaded_scenes["structure"] (src/vk_engine.cpp:192-198)
+    auto loaded = load_gltf_meshes(&eng, gltf);
+    if (!loaded) {
+      fprintf(stderr, "%s\n", eng.error.c_str());
+      return 1;
+    }
+    eng.loaded_scenes["structure"] = loaded;
+    eng.main_camera.position = {cam[0], cam[1], cam[2]};
+    eng.main_camera.pitch = cam[3];
+    eng.main_camera.yaw = cam[4];
+    size_t surfaces = 0;
+    for (auto& m : loaded->meshes) surfaces += m->surfaces.size();
+    printf("gltf %s: %zu meshes %zu surfaces %zu nodes %zu top nodes %zu materials %zu images %zu samplers\n", gltf.c_str(),
+           loaded->meshes.size(), surfaces, loaded->nodes.size(), loaded->top_nodes.size(), loaded->materials.size(),
+           loaded->images.size(), loaded->samplers.size());
+  } else {
   // "load_gltf_meshes" by hand: one mesh with two primitives (two cubes' worth of geometry in one buffer)
   auto mesh = std::make_shared<MeshAsset>();
   mesh->name = "cubes";
@@ -116,6 +157,7 @@ int main(int argc, char** argv) {
   root->refresh_transform(svrm::identity());  // src/vk_loader.cpp:430-435
   eng.loaded_scenes["structure"] = scene;
   eng.main_camera.position = {0, 0, 0};
+  }
 
   for (int f = 0; f < frames; f++) {
     eng.update_scene();
@@ -141,6 +183,12 @@ int main(int argc, char** argv) {
     }
     dump(prefix + ".color", color.data(), color.size());
     dump(prefix + ".depth", depth.data(), depth.size());
+    std::vector<uint8_t> swap;  // what copy_image leaves in the swapchain image (src/vk_engine.cpp:1277)
+    if (!eng.read_swapchain(swap)) {
+      fprintf(stderr, "swapchain readback failed: %s\n", eng.error.c_str());
+      return 1;
+    }
+    dump(prefix + ".swapchain", swap.data(), swap.size());
   }
   eng.cleanup();
   return 0;

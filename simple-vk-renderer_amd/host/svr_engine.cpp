@@ -26,7 +26,7 @@ bool SvrApi::load(const std::string& path, std::string* err) {
   SVR_LOAD(svr_create) SVR_LOAD(svr_destroy) SVR_LOAD(svr_upload_mesh) SVR_LOAD(svr_create_image)
   SVR_LOAD(svr_create_sampler) SVR_LOAD(svr_write_material) SVR_LOAD(svr_clear_color) SVR_LOAD(svr_draw_geometry)
   SVR_LOAD(svr_sync) SVR_LOAD(svr_read_color) SVR_LOAD(svr_read_depth) SVR_LOAD(svr_get_stats) SVR_LOAD(svr_last_error)
-  SVR_LOAD(svr_backend_name)
+  SVR_LOAD(svr_backend_name) SVR_LOAD(svr_draw_background) SVR_LOAD(svr_read_swapchain) SVR_LOAD(svr_copy_to_swapchain)
 #undef SVR_LOAD
   return ok;
 }
@@ -198,9 +198,30 @@ void SvrEngine::update_scene() {  // src/vk_engine.cpp:1479-1512
   stats.scene_update_time = std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count() / 1000.f;
 }
 
-bool SvrEngine::draw_background() {  // src/vk_engine.cpp:1341-1355 with effect.data = (1,1,1,1) twice
-  const float white[4] = {1, 1, 1, 1};
-  if (api.svr_clear_color(ctx, white)) {
+bool SvrEngine::draw_background() {  // src/vk_engine.cpp:1341-1355: dispatch the current ComputeEffect
+  if (background_effects.empty()) {  // init_background_pipelines, src/vk_engine.cpp:977-989
+    ComputeEffect gradient, sky;
+    gradient.name = "gradient";
+    gradient.effect = SVR_BACKGROUND_GRADIENT;
+    for (int k = 0; k < 8; k++) gradient.data[k] = 1.0f;
+    sky.name = "sky";
+    sky.effect = SVR_BACKGROUND_SKY;
+    sky.data[0] = 0.1f; sky.data[1] = 0.2f; sky.data[2] = 0.4f; sky.data[3] = 0.97f;
+    background_effects.push_back(gradient);
+    background_effects.push_back(sky);
+  }
+  const ComputeEffect& effect = background_effects[(size_t)current_background_effect % background_effects.size()];
+  if (api.svr_draw_background(ctx, effect.effect, effect.data)) {
+    error = api.svr_last_error();
+    return false;
+  }
+  return true;
+}
+
+bool SvrEngine::read_swapchain(std::vector<uint8_t>& out) {
+  uint32_t sw = swapchain_width ? swapchain_width : width, sh = swapchain_height ? swapchain_height : height;
+  out.resize((size_t)sw * sh * 4);
+  if (api.svr_read_swapchain(ctx, sw, sh, SVR_SWAPCHAIN_B8G8R8A8, out.data(), out.size())) {
     error = api.svr_last_error();
     return false;
   }

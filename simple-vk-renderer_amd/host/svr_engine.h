@@ -31,6 +31,7 @@ struct SvrApi {
   SVR_FN(svr_create) SVR_FN(svr_destroy) SVR_FN(svr_upload_mesh) SVR_FN(svr_create_image) SVR_FN(svr_create_sampler)
   SVR_FN(svr_write_material) SVR_FN(svr_clear_color) SVR_FN(svr_draw_geometry) SVR_FN(svr_sync) SVR_FN(svr_read_color)
   SVR_FN(svr_read_depth) SVR_FN(svr_get_stats) SVR_FN(svr_last_error) SVR_FN(svr_backend_name)
+  SVR_FN(svr_draw_background) SVR_FN(svr_read_swapchain) SVR_FN(svr_copy_to_swapchain)
 #undef SVR_FN
   bool load(const std::string& path, std::string* err);
   void unload();
@@ -87,12 +88,24 @@ struct LoadedScene {  // LoadedGLTF, src/vk_loader.h:33-57
   std::vector<std::shared_ptr<MeshAsset>> meshes;
   std::vector<std::shared_ptr<Node>> nodes, top_nodes;
   std::vector<std::shared_ptr<MaterialInstance>> materials;
+  std::vector<SvrImage> images;      // file-owned images (not the engine defaults), LoadedGLTF::images
+  std::vector<SvrSampler> samplers;  // LoadedGLTF::samplers
   void Draw(const mat4& top_matrix, DrawContext& ctx);
+};
+
+struct ComputeEffect {  // src/vk_engine.h ComputeEffect: name + ComputePushConstants (4 x vec4)
+  const char* name = "";
+  int effect = SVR_BACKGROUND_GRADIENT;
+  float data[16] = {0};
 };
 
 // GLTF loader's bounds rule (src/vk_loader.cpp:366-375): min/max start at the primitive's first vertex
 // but run over every vertex accumulated in the mesh so far
 SvrBounds loader_bounds(const std::vector<SvrVertex>& mesh_vertices_so_far, size_t initial_vtx);
+
+struct SvrEngine;
+// load_gltf_meshes (src/vk_loader.cpp:162-437): .glb or .gltf -> uploaded scene; nullptr + engine->error on failure
+std::shared_ptr<LoadedScene> load_gltf_meshes(SvrEngine* engine, const std::string& file_path);
 
 struct SvrEngine {
   SvrApi api;
@@ -117,9 +130,15 @@ struct SvrEngine {
   std::shared_ptr<MaterialInstance> write_material(int pass, const float color_factors[4], SvrImage image, SvrSampler sampler);
   void init_camera();
   void update_scene();
+  // init_background_pipelines (src/vk_engine.cpp:920-1000): gradient (white, white) and sky (0.1,0.2,0.4,0.97)
+  std::vector<ComputeEffect> background_effects;
+  int current_background_effect = 0;
+  uint32_t swapchain_width = 0, swapchain_height = 0;  // _swap_chain_extent; 0 = the draw extent
   bool draw_background();
   bool draw_geometry();
-  bool draw();  // update_scene -> draw_background -> draw_geometry (the blit/ImGui/present steps have no counterpart)
+  bool draw();  // update_scene -> draw_background -> draw_geometry (ImGui/present have no counterpart)
+  // the swapchain image of the frame just drawn: vkutil::copy_image at src/vk_engine.cpp:1277 (B8G8R8A8)
+  bool read_swapchain(std::vector<uint8_t>& out);
   bool read_color_rgba16f(std::vector<uint16_t>& out);
   bool read_depth(std::vector<float>& out);
 };

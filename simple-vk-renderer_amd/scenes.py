@@ -50,8 +50,11 @@ class MeshAsset:
         mx = np.maximum(first, allpos.max(axis=0))
         origin = (mx + mn) / f32(2)
         extents = (mx - mn) / f32(2)
-        radius = f32(math.sqrt(float(np.dot(extents.astype(np.float64), extents.astype(np.float64)))))
-        self.surfaces.append(Surface(start, indices.size, material, origin.astype(f32), radius, extents.astype(f32)))
+        e2 = (extents * extents).astype(f32)  # glm::length = sqrt(dot): fp32 products, (x + y) + z, fp32 sqrt
+        radius = f32(np.sqrt(f32(f32(e2[0] + e2[1]) + e2[2])))
+        surf = Surface(start, indices.size, material, origin.astype(f32), radius, extents.astype(f32))
+        surf.first_vertex, surf.n_vertices = initial_vtx, n  # the primitive's own slice (gltf_io.write_glb)
+        self.surfaces.append(surf)
 
 
 class Scene:
