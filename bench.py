@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--tex-size", type=int, default=1024)
     ap.add_argument("--instances", type=int, default=1, help="16 = BASELINE config 5's 4x4 instancing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-fp16", action="store_true", help="N > 1: all-gather the RGBA16F target instead of the swapchain image")
     ap.add_argument("--cpu-frames", type=int, default=3)
     return ap.parse_args()
 
@@ -109,7 +110,9 @@ def main():
     sc = S.sponza_like(lod=args.lod, tex_size=args.tex_size)
     r = hip.create(W, H, A.COLOR_RGBA16F, device=local_rank)
     r.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    slots = [D.ShardedFrame(torch, r, rank, world, dev, A.COLOR_RGBA16F) for _ in range(2)]
+    # N > 1: the presentable B8G8R8A8 image is what the ranks exchange (4 B/px; --gather-fp16 sends the target)
+    present = world > 1 and not args.gather_fp16
+    slots = [D.ShardedFrame(torch, r, rank, world, dev, A.COLOR_RGBA16F, present=present) for _ in range(2)]
     handles = sc.upload(r)
     inst = S.config5_instances() if args.instances == 16 else None
     opaque, transparent = sc.render_objects(handles, instance_transforms=inst)
@@ -190,7 +193,8 @@ def main():
                                    f" (BASELINE configs[{4 if args.instances == 16 else 3}])",
                        "width": W, "height": H, "triangles": counts_scene["triangles"] * args.instances,
                        "draws": int(len(opaque) + len(transparent)), "textures": f"25 x {args.tex_size}^2 RGBA8 mipmapped",
-                       "parallelism": f"row bands x{world} + all_gather" if world > 1 else "single GPU"},
+                       "parallelism": (f"row bands x{world} + all_gather of the " + ("B8G8R8A8 swapchain image" if present else "RGBA16F target"))
+                                      if world > 1 else "single GPU"},
             "frames_per_s": fps,
             "shaded_fragments_per_frame": shaded, "rasterized_fragments_per_frame": rasterized,
             "rasterized_fragments_per_s": rasterized * fps,

@@ -197,8 +197,10 @@ int svr_draw_background(SvrContext* ctx, int effect, const float data[16]);
  * 1268-1280): LINEAR-filter blit of the whole colour target to a dst_width x dst_height image of the
  * swapchain's format (B8G8R8A8_UNORM, src/vk_engine.cpp:553) — identity-sized unless the window was
  * resized.  dst_dev: device memory, dst_width*dst_height*4 bytes, row-major (stands for the
- * swapchain image); stream-ordered like a pass.  svr_read_swapchain does the same into an internal
- * image and copies it to the host (tests, screenshots). */
+ * swapchain image); stream-ordered like a pass.  With the identity extent only the rows of the current
+ * scissor are written (a rank of the multi-GPU path presents its band; full scissor = everything); a
+ * scaled blit always writes the whole image.  svr_read_swapchain blits the whole image into an
+ * internal buffer and copies it to the host (tests, screenshots). */
 enum SvrSwapchainFormat { SVR_SWAPCHAIN_B8G8R8A8 = 0, SVR_SWAPCHAIN_R8G8B8A8 = 1 };
 int svr_copy_to_swapchain(SvrContext* ctx, void* dst_dev, uint32_t dst_width, uint32_t dst_height, int dst_format);
 int svr_read_swapchain(SvrContext* ctx, uint32_t dst_width, uint32_t dst_height, int dst_format, void* dst_host,

@@ -1016,9 +1016,9 @@ int svr_draw_background(SvrContext* ctx, int effect, const float data[16]) {
 }
 
 // ---- vkutil::copy_image (src/vk_images.cpp:33-64): LINEAR blit to the swapchain format  (contract C16)
-static int blit_to(SvrContext* ctx, uint32_t dw, uint32_t dh, int fmt, uint8_t* dst) {
+static int blit_to(SvrContext* ctx, uint32_t dw, uint32_t dh, int fmt, uint8_t* dst, uint32_t row_first, uint32_t n_rows) {
   const float su = (float)ctx->W / (float)dw, sv = (float)ctx->H / (float)dh;
-  for (uint32_t j = 0; j < dh; j++)
+  for (uint32_t j = row_first; j < row_first + n_rows; j++)
     for (uint32_t i = 0; i < dw; i++) {
       float u = ((float)i + 0.5f) * su - 0.5f, v = ((float)j + 0.5f) * sv - 0.5f;
       float fu = std::floor(u), fv = std::floor(v);
@@ -1052,12 +1052,17 @@ int svr_read_swapchain(SvrContext* ctx, uint32_t dw, uint32_t dh, int fmt, void*
   if (fmt != SVR_SWAPCHAIN_B8G8R8A8 && fmt != SVR_SWAPCHAIN_R8G8B8A8)
     return fail(SVR_ERR_INVALID_ARGUMENT, "svr_read_swapchain: unknown format");
   if (bytes < (size_t)dw * dh * 4) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_read_swapchain: buffer too small");
-  return blit_to(ctx, dw, dh, fmt, (uint8_t*)dst);
+  return blit_to(ctx, dw, dh, fmt, (uint8_t*)dst, 0, dh);
 }
 
 // the oracle has no device memory: the "swapchain image" is host memory here
 int svr_copy_to_swapchain(SvrContext* ctx, void* dst, uint32_t dw, uint32_t dh, int fmt) {
-  return svr_read_swapchain(ctx, dw, dh, fmt, dst, (size_t)dw * dh * 4);
+  if (!ctx || !dst) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_copy_to_swapchain: null argument");
+  if (dw == 0 || dh == 0 || dw > 16384 || dh > 16384) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_copy_to_swapchain: extent must be in 1..16384");
+  if (fmt != SVR_SWAPCHAIN_B8G8R8A8 && fmt != SVR_SWAPCHAIN_R8G8B8A8)
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_copy_to_swapchain: unknown format");
+  const bool identity = dw == ctx->W && dh == ctx->H;  // identity extent: the scissor's rows only
+  return blit_to(ctx, dw, dh, fmt, (uint8_t*)dst, identity ? ctx->sy : 0u, identity ? ctx->sh : dh);
 }
 
 int svr_set_scissor(SvrContext* ctx, uint32_t x, uint32_t y, uint32_t w, uint32_t h) {

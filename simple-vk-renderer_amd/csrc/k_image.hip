@@ -199,12 +199,13 @@ __device__ __forceinline__ float4 load_target(const void* color, int fmt, size_t
   return make_float4((float)(t & 0xffu) * k, (float)((t >> 8) & 0xffu) * k, (float)((t >> 16) & 0xffu) * k, (float)(t >> 24) * k);
 }
 __global__ __launch_bounds__(256) void blit_kernel(const void* color, int fmt, uint32_t W, uint32_t H, uint32_t* dst, uint32_t dw,
-                                                   uint32_t dh, int dst_format, const uint32_t* poison) {
+                                                   uint32_t dh, uint32_t row_first, uint32_t n_rows, int dst_format,
+                                                   const uint32_t* poison) {
   if (*poison) return;
   const float su = (float)W / (float)dw, sv = (float)H / (float)dh;
-  const uint32_t n = dw * dh;
-  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
-    uint32_t i = idx % dw, j = idx / dw;
+  const uint32_t n = dw * n_rows;  // destination rows [row_first, row_first + n_rows)
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    uint32_t i = k % dw, j = row_first + k / dw, idx = j * dw + i;
     float u = ((float)i + 0.5f) * su - 0.5f, v = ((float)j + 0.5f) * sv - 0.5f;
     float fu = floorf(u), fv = floorf(v);
     float a = u - fu, b = v - fv;
@@ -223,10 +224,10 @@ __global__ __launch_bounds__(256) void blit_kernel(const void* color, int fmt, u
     dst[idx] = dst_format == SVR_SWAPCHAIN_B8G8R8A8 ? (bl | (g << 8) | (r << 16) | (al << 24)) : (r | (g << 8) | (bl << 16) | (al << 24));
   }
 }
-void launch_blit(const void* color, int color_format, uint32_t W, uint32_t H, void* dst, uint32_t dw, uint32_t dh, int dst_format,
-                 const uint32_t* poison, hipStream_t s) {
-  hipLaunchKernelGGL(blit_kernel, dim3(stream_grid(dw * dh)), dim3(256), 0, s, color, color_format, W, H, (uint32_t*)dst, dw, dh,
-                     dst_format, poison);
+void launch_blit(const void* color, int color_format, uint32_t W, uint32_t H, void* dst, uint32_t dw, uint32_t dh, uint32_t row_first,
+                 uint32_t n_rows, int dst_format, const uint32_t* poison, hipStream_t s) {
+  hipLaunchKernelGGL(blit_kernel, dim3(stream_grid(dw * n_rows)), dim3(256), 0, s, color, color_format, W, H, (uint32_t*)dst, dw, dh,
+                     row_first, n_rows, dst_format, poison);
 }
 
 void launch_rgba16f_to_rgba8(const void* src, void* dst, uint32_t n_pixels, hipStream_t s) {

@@ -442,7 +442,8 @@ int submit_clear(SvrContext* ctx, const SvrContext::LoggedOp& op) {  // every lo
   else if (op.fill_kind == 1)
     launch_background(op.target, op.clear_fmt, op.tw, op.th, op.y_first, op.n_rows, op.bg_effect, op.bg_data, ctx->d_poison, ctx->stream);
   else
-    launch_blit(op.target, op.clear_fmt, op.tw, op.th, op.blit_dst, op.blit_w, op.blit_h, op.blit_fmt, ctx->d_poison, ctx->stream);
+    launch_blit(op.target, op.clear_fmt, op.tw, op.th, op.blit_dst, op.blit_w, op.blit_h, op.y_first, op.n_rows, op.blit_fmt, ctx->d_poison,
+                ctx->stream);
   HIPCHK(hipGetLastError());
   return SVR_OK;
 }
@@ -955,6 +956,10 @@ int svr_copy_to_swapchain(SvrContext* ctx, void* dst_dev, uint32_t dw, uint32_t 
   op.blit_w = dw;
   op.blit_h = dh;
   op.blit_fmt = fmt;
+  // identity extent: the rows of the scissor (a rank of the multi-GPU path presents its band); scaled: everything
+  const bool identity = dw == ctx->W && dh == ctx->H;
+  op.y_first = identity ? ctx->sy : 0u;
+  op.n_rows = identity ? ctx->sh : dh;
   return submit_clear(ctx, op);
 }
 
@@ -964,7 +969,7 @@ int svr_read_swapchain(SvrContext* ctx, uint32_t dw, uint32_t dh, int fmt, void*
   if (int e = use_device(ctx)) return e;
   if (int e = finish_pending(ctx)) return e;  // the read-back is a fence
   if (int e = ctx->d_cvt.ensure((size_t)dw * dh * 4)) return e;
-  launch_blit(ctx->color, ctx->fmt, ctx->W, ctx->H, ctx->d_cvt.p, dw, dh, fmt, ctx->d_poison, ctx->stream);
+  launch_blit(ctx->color, ctx->fmt, ctx->W, ctx->H, ctx->d_cvt.p, dw, dh, 0, dh, fmt, ctx->d_poison, ctx->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(dst_host, ctx->d_cvt.p, (size_t)dw * dh * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));

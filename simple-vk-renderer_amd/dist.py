@@ -7,8 +7,11 @@ nothing here translates reference code; it is the screen-space decomposition of 
   - scene (meshes, textures, materials) replicated on every rank — Sponza-scale is ~150 MB of 288 GB;
   - rank r owns rows [r*band, (r+1)*band) with band = ceil(H / world): svr_set_scissor clips geometry,
     binning and the tile grid to the band, pixels of a band never depend on another band;
-  - each rank renders straight into its slice of a full-frame tensor, then
-    all_gather_into_tensor(frame, my_band) in place: every rank ends up with the whole _draw_image;
+  - each rank renders straight into its rows of a full-frame _draw_image tensor, presents them
+    (svr_copy_to_swapchain, identity extent: the scissor's rows) into its slice of a full-frame
+    B8G8R8A8 swapchain tensor, then all_gather_into_tensor(swapchain, my_band) in place: every rank
+    ends up with the whole presentable frame at 4 bytes per pixel, as SURVEY §8e sizes the exchange
+    (present=False gathers the RGBA16F _draw_image itself, 8 bytes per pixel);
   - two frames in flight (the reference keeps FRAME_OVERLAP = 3, src/vk_engine.h:77): the gather of
     frame i runs on the collective's stream while frame i+1 renders.
 xGMI is point-to-point (7 links per GPU): an all-gather of equal bands is one hop per peer and the
@@ -32,7 +35,7 @@ class ShardedFrame:
     """One frame slot: full-frame colour/depth tensors padded to world*band rows, this rank's band view,
     and the scissor that makes the renderer fill exactly that band."""
 
-    def __init__(self, torch, renderer, rank, world, device, color_format, bind=True):
+    def __init__(self, torch, renderer, rank, world, device, color_format, bind=True, present=True):
         from . import abi
         self.torch, self.r, self.rank, self.world = torch, renderer, rank, world
         self.W, self.H = renderer.width, renderer.height
@@ -41,7 +44,10 @@ class ShardedFrame:
         cdtype = torch.float16 if color_format == abi.COLOR_RGBA16F else torch.uint8
         self.color = torch.zeros((hp, self.W, 4), dtype=cdtype, device=device)
         self.depth = torch.zeros((hp, self.W), dtype=torch.float32, device=device)
-        self.flat = self.color.view(-1)
+        self.present = present
+        # what travels: the swapchain image (uint8 BGRA) or the colour target itself
+        self.swapchain = torch.zeros((hp, self.W, 4), dtype=torch.uint8, device=device) if present else None
+        self.flat = (self.swapchain if present else self.color).view(-1)
         n = self.band * self.W * 4
         self.my_band = self.flat[rank * n:(rank + 1) * n]
         self.bound = bind
@@ -61,7 +67,10 @@ class ShardedFrame:
 
     def gather(self, dist, async_op=True):
         """Exchange the finished bands; in place (input is the rank's slice of the output)."""
-        if not self.bound:  # test path (CPU oracle owns its targets): copy the band out first
+        if self.present:
+            if self.rows > 0:  # vkutil::copy_image of this rank's rows (the scissor is still the band)
+                self.r.copy_to_swapchain(self.swapchain.data_ptr(), self.W, self.H, 0)
+        elif not self.bound:  # test path (CPU oracle owns its targets): copy the band out first
             col = self.r.read_color()
             t = self.torch.from_numpy(col.view(np.float16) if col.dtype == np.uint16 else col)
             self.color[self.y0:self.y0 + self.rows].copy_(t[self.y0:self.y0 + self.rows])
@@ -90,8 +99,13 @@ class ShardedFrame:
             self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX)  # the re-send is a collective: all ranks or none
             self._replays = now
             if int(flag.item()):
+                if self.present and self.rows > 0:  # the replayed rows have to be presented again first
+                    self.r.bind_targets(self.color.data_ptr(), self.depth.data_ptr())
+                    self.r.set_scissor(0, self.y0, self.W, self.rows)
+                    self.r.copy_to_swapchain(self.swapchain.data_ptr(), self.W, self.H, 0)
+                    self.r.sync()
                 self._dist.all_gather_into_tensor(self.flat, self.my_band)
 
     def image(self):
-        """The gathered frame without the padding rows."""
-        return self.color[:self.H]
+        """The gathered frame without the padding rows (B8G8R8A8 swapchain bytes, or the colour target)."""
+        return (self.swapchain if self.present else self.color)[:self.H]

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, width, height, out_dir):
+def _worker(rank, world, port, width, height, out_dir, present):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,7 +34,7 @@ def _worker(rank, world, port, width, height, out_dir):
         ora = T.load_oracle()
         D = g.load_package().dist
         r, scene, opaque, transparent = T.setup_sponza(ora, width, height, lod=8, tex_size=32)
-        slots = [D.ShardedFrame(torch, r, rank, world, torch.device("cpu"), pkg.abi.COLOR_RGBA16F, bind=False)
+        slots = [D.ShardedFrame(torch, r, rank, world, torch.device("cpu"), pkg.abi.COLOR_RGBA16F, bind=False, present=present)
                  for _ in range(2)]
         for f in range(3):  # three frames through two slots, asynchronous gathers
             s = slots[f % 2]
@@ -46,7 +46,8 @@ def _worker(rank, world, port, width, height, out_dir):
             s.gather(dist, async_op=True)
         for s in slots:
             s.finish()
-        img = slots[0].image().numpy().view(np.uint16)
+        img = slots[0].image().numpy()
+        img = img if present else img.view(np.uint16)
         np.save(os.path.join(out_dir, f"rank{rank}.npy"), img)
         r.close()
         dist.barrier()
@@ -54,13 +55,15 @@ def _worker(rank, world, port, width, height, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("size", [(96, 54), (80, 45)])
-def test_band_allgather_world2(tmp_path, oracle, size):
+@pytest.mark.parametrize("size,present", [((96, 54), True), ((80, 45), True), ((80, 45), False)])
+def test_band_allgather_world2(tmp_path, oracle, size, present):
+    """present: the B8G8R8A8 swapchain image travels (bench default); else the RGBA16F target."""
     torch = pytest.importorskip("torch")
     import torch.multiprocessing as mp
     w, h = size
-    mp.spawn(_worker, args=(2, _free_port(), w, h, str(tmp_path)), nprocs=2, join=True)
-    ref = T.render_sponza(oracle, w, h, lod=8, tex_size=32)["color"]
+    mp.spawn(_worker, args=(2, _free_port(), w, h, str(tmp_path), present), nprocs=2, join=True)
+    full = T.render_sponza(oracle, w, h, lod=8, tex_size=32)
+    ref = full["rgba8"][..., [2, 1, 0, 3]] if present else full["color"]
     for rank in range(2):
         got = np.load(tmp_path / f"rank{rank}.npy")
         assert got.shape == ref.shape

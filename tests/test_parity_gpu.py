@@ -161,6 +161,25 @@ def test_copy_to_swapchain_device_image(hip):
     r.close()
 
 
+def test_identity_blit_writes_the_scissor_rows(hip):
+    """The multi-GPU present step: an identity-sized svr_copy_to_swapchain writes exactly the rows of
+    the scissor, so bands presented one by one assemble the whole swapchain image."""
+    import torch
+    r = hip.create(320, 200)
+    r.draw_background(A.BACKGROUND_SKY, A.SKY_DEFAULT)
+    r.draw_colored_triangle()
+    whole = r.read_swapchain(320, 200, A.SWAPCHAIN_B8G8R8A8)
+    dst = torch.full((200, 320, 4), 7, dtype=torch.uint8, device="cuda")
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    for y0, n in ((0, 67), (67, 67), (134, 66)):
+        r.set_scissor(0, y0, 320, n)
+        r.copy_to_swapchain(dst.data_ptr(), 320, 200, A.SWAPCHAIN_B8G8R8A8)
+        r.sync()
+        got = dst.cpu().numpy()
+        assert np.array_equal(got[:y0 + n], whole[:y0 + n]) and np.all(got[y0 + n:] == 7)
+    r.close()
+
+
 def test_rgba8_target(hip, oracle):
     a, b = both(T.render_sponza, hip, oracle, 320, 180, lod=8, tex_size=64, color_format=A.COLOR_RGBA8, instrument=True)
     assert_same(a, b, "config3 rgba8")
