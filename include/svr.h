@@ -250,6 +250,11 @@ int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint
  * process; results are identical either way).  bit0: tile kernel walks tiles row-major instead of
  * heaviest-first.  bit1: geometry + binning run on the caller's stream instead of overlapping the
  * previous pass's tile stage on an internal stream.
+ * SVR_OPT_DEVICE_FLATTEN: where svr_draw_geometry's host half runs — is_visible, the sort and the
+ * per-object draw records (src/vk_engine.cpp:1361-1378, 1412-1457).  0 (default): on the device from
+ * 2048 objects up, on the host below; 1: always on the device; 2: always on the host.  Same frames
+ * either way.  Device-side, drawcall_count / triangle_count / culled_draws are not known when
+ * svr_draw_geometry returns (its out_stats holds 0 there): svr_get_stats has them after the pass.
  * SVR_OPT_QUEUE_CAPS: initial capacity (entries) of the pass-internal queues — clip queue, clipper
  * output records, bin/pair lists — instead of the generous defaults; 0 restores the defaults.  A pass
  * that overflows a queue writes nothing, and is replayed with grown queues before its results can be
@@ -259,7 +264,8 @@ enum SvrOption {
   SVR_OPT_KERNEL_TIMING = 2,
   SVR_OPT_TILE_CYCLES = 3,
   SVR_OPT_TUNING = 4,
-  SVR_OPT_QUEUE_CAPS = 5
+  SVR_OPT_QUEUE_CAPS = 5,
+  SVR_OPT_DEVICE_FLATTEN = 6
 };
 int svr_set_option(SvrContext* ctx, int option, int64_t value);
 

@@ -1225,7 +1225,7 @@ int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint
 int svr_set_option(SvrContext* ctx, int option, int64_t) {
   if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
   if (option != SVR_OPT_COUNT_FRAGMENTS && option != SVR_OPT_KERNEL_TIMING && option != SVR_OPT_TILE_CYCLES &&
-      option != SVR_OPT_TUNING && option != SVR_OPT_QUEUE_CAPS)
+      option != SVR_OPT_TUNING && option != SVR_OPT_QUEUE_CAPS && option != SVR_OPT_DEVICE_FLATTEN)
     return fail(SVR_ERR_INVALID_ARGUMENT, "svr_set_option: unknown option");
   return SVR_OK;  // the oracle always counts and has no kernels to time
 }

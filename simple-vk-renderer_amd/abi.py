@@ -70,6 +70,7 @@ OPT_KERNEL_TIMING = 2
 OPT_TILE_CYCLES = 3
 OPT_TUNING = 4
 OPT_QUEUE_CAPS = 5
+OPT_DEVICE_FLATTEN = 6
 BACKGROUND_GRADIENT, BACKGROUND_SKY = 0, 1
 SWAPCHAIN_B8G8R8A8, SWAPCHAIN_R8G8B8A8 = 0, 1
 GRADIENT_DEFAULT = (1.0, 1.0, 1.0, 1.0) * 2 + (0.0,) * 8       # src/vk_engine.cpp:981-982

@@ -29,7 +29,9 @@ __device__ __forceinline__ void shade_corner(const DrawDesc& d, uint32_t kind, c
 __global__ __launch_bounds__(256) void setup_kernel(FrameParams P) {
   uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   uint32_t lane = threadIdx.x & 63;
-  const bool live = gw < P.n_chunks;  // wave-uniform; dead waves of the last block only attend the barriers
+  // device-flattened passes: the grid was sized by the host's upper bound, the real count is on the device
+  const uint32_t n_chunks = P.flatten ? P.counters->flat_chunks : P.n_chunks;
+  const bool live = gw < n_chunks;  // wave-uniform; dead waves only attend the barriers
   WaveChunk ch = P.chunks[live ? gw : 0u];
   const DrawDesc& d = P.draws[ch.draw];
   uint32_t tri = live ? ch.first_tri + lane : 0xffffffffu;

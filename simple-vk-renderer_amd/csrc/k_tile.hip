@@ -914,7 +914,8 @@ __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
 // Instrumented passes only: the counters go to the host (pinned, device-visible) by a one-wave kernel
 // behind the tile kernel.  (A D2H copy packet there costs ~15 us of stream time; a last-workgroup-
 // reports epilogue in the tile kernel holds every workgroup's slot for an atomic round trip: +15 %.)
-// Uninstrumented passes report nothing: the host learns of an overflow through host_failed_seq.
+// Other passes report nothing (the host learns of an overflow through host_failed_seq), except
+// device-flattened ones, whose draw / triangle / culled counts only exist on the device.
 __global__ __launch_bounds__(64) void report_kernel(FrameParams P) {
   if (threadIdx.x < sizeof(Counters) / 4)
     __hip_atomic_store(reinterpret_cast<uint32_t*>(P.host_counters) + threadIdx.x,
@@ -934,7 +935,7 @@ void launch_tiles(const FrameParams& P, int color_format, bool count_fragments, 
     else
       hipLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA8, false>), grid, block, 0, s, P);
   }
-  if (count_fragments) hipLaunchKernelGGL(report_kernel, dim3(1), dim3(64), 0, s, P);
+  if (count_fragments || P.flatten) hipLaunchKernelGGL(report_kernel, dim3(1), dim3(64), 0, s, P);
 }
 
 }  // namespace svr

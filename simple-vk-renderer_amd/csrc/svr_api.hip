@@ -115,12 +115,16 @@ struct SvrContext {
   std::vector<MaterialRes> materials;
   DevBuf tex_table;  // TexBinding[materials + 1]; last slot = scratch binding of svr_draw_tex_image
   size_t tex_slots = 0;
+  // resource tables of the device flatten pass (k_flatten.hip), rebuilt when a mesh / material was added
+  DevBuf mesh_table, mat_table;
+  size_t mesh_table_n = 0, mat_table_n = 0;
+  int device_flatten = 0;  // SVR_OPT_DEVICE_FLATTEN: 0 auto (>= 2048 objects), 1 always, 2 never
 
   // Per-pass device buffers, double-buffered: the geometry+binning stage of pass N+1 runs on the
   // internal stream `gstream` while the tile stage of pass N still reads set N on the caller's
   // stream.  ev_bin: set filled (recorded on gstream); ev_tile: set consumed (the pass's op_done event).
   struct PassSet {
-    DevBuf inputs, recs, clipq, bigq, tiles, bins, pairs;  // inputs = DrawDesc[] then WaveChunk[] (one H2D copy)
+    DevBuf inputs, recs, clipq, bigq, tiles, bins, pairs, flat;  // flat: keys / triangle counts / chunk bases of k_flatten  // inputs = DrawDesc[] then WaveChunk[] (one H2D copy)
     hipEvent_t ev_bin = nullptr;
     hipEvent_t ev_tile = nullptr;  // not owned: op_done of the pass that used the set last
     bool used = false;
@@ -148,6 +152,9 @@ struct SvrContext {
     int blit_fmt = 0;
     FrameParams P{};  // pass: parameters as recorded + its draw list
     std::vector<DrawDesc> draws;
+    // device-flattened pass: the caller's objects (opaque, then transparent) instead of a draw list
+    std::vector<SvrRenderObject> objects;
+    uint32_t n_opaque_obj = 0, n_transparent_obj = 0;
   };
   std::deque<LoggedOp> log;
   hipEvent_t op_done[MAX_OPS] = {};
@@ -302,9 +309,9 @@ int harvest_timing(SvrContext* ctx, int slot) {
   return SVR_OK;
 }
 
-// head of a set's tile buffer: Counters (64 B) + 80 class counters (FrameParams::cls_count), then tile_count
-constexpr size_t TILE_HEAD_BYTES = 64 + 80 * sizeof(uint32_t);
-static_assert(sizeof(Counters) == 64 && TILE_HEAD_BYTES % 16 == 0, "tile buffer head layout");
+// head of a set's tile buffer: Counters (96 B) + 80 class counters (FrameParams::cls_count), then tile_count
+constexpr size_t TILE_HEAD_BYTES = sizeof(Counters) + 80 * sizeof(uint32_t);
+static_assert(TILE_HEAD_BYTES % 16 == 0, "tile buffer head layout");
 
 // size the per-pass buffers for P.n_tris and the current capacities, fill the pointers
 int bind_pass_buffers(SvrContext* ctx, FrameParams& P, int set_index) {
@@ -340,7 +347,8 @@ int bind_pass_buffers(SvrContext* ctx, FrameParams& P, int set_index) {
 // (report_kernel) -> op_done.  The caller sees stream order (everything it enqueued before the call precedes the tile
 // stage, the only one that touches the targets); stage 1 depends on host inputs alone, so it overlaps
 // the tile stages of the passes before it.
-int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& draws, int op_slot, uint32_t seq, bool pipe) {
+int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& draws, int op_slot, uint32_t seq, bool pipe,
+                const SvrContext::LoggedOp* flat_op = nullptr) {
   // queue capacities: generous first guesses; overflow -> replay (recover_from_overflow)
   if (ctx->debug_caps) {  // SVR_OPT_QUEUE_CAPS: start tiny so that tests reach the replay path
     ctx->clip_cap = std::max<uint32_t>(ctx->clip_cap, ctx->debug_caps);
@@ -356,24 +364,31 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   SvrContext::PassSet& set = ctx->sets[set_index];
   hipStream_t s = ctx->stream, g = pipe ? ctx->gstream : ctx->stream;
   // per-pass inputs: draws + chunks through pinned staging, one copy
-  size_t draw_bytes = draws.size() * sizeof(DrawDesc), chunk_bytes = (size_t)P.n_chunks * sizeof(WaveChunk);
+  const size_t n_objects = flat_op ? flat_op->objects.size() : 0;
+  size_t draw_bytes = (flat_op ? n_objects : draws.size()) * sizeof(DrawDesc), chunk_bytes = (size_t)P.n_chunks * sizeof(WaveChunk);
   if (int e = set.inputs.ensure(std::max<size_t>(draw_bytes + chunk_bytes + 16, 256))) return e;
+  if (flat_op)
+    if (int e = set.flat.ensure(n_objects * 16 + 64)) return e;
   if (int e = bind_pass_buffers(ctx, P, set_index)) return e;
   // this set was last read by the tile stage of NSETS passes ago
   if (pipe && set.used) HIPCHK(hipStreamWaitEvent(g, set.ev_tile, 0));
   void* stage = nullptr;
-  if (int e = stage_buffer(ctx, op_slot, draw_bytes + chunk_bytes + 64, &stage)) return e;
+  if (int e = stage_buffer(ctx, op_slot, (flat_op ? n_objects * sizeof(SvrRenderObject) : draw_bytes + chunk_bytes) + 64, &stage)) return e;
   P.host_counters = &ctx->h_counters[op_slot];
   P.op_seq = seq;
-  std::memcpy(stage, draws.data(), draw_bytes);
-  WaveChunk* ch = reinterpret_cast<WaveChunk*>((char*)stage + draw_bytes);
-  size_t ci = 0;
-  for (size_t di = 0; di < draws.size(); di++)
-    for (uint32_t t = 0; t < draws[di].tri_count; t += 64u) {
-      ch[ci].draw = (uint32_t)di;
-      ch[ci].first_tri = t;
-      ci++;
-    }
+  if (flat_op) {  // the objects themselves are the input; cull, sort, draw records and chunks happen on the device
+    std::memcpy(stage, flat_op->objects.data(), n_objects * sizeof(SvrRenderObject));
+  } else {
+    std::memcpy(stage, draws.data(), draw_bytes);
+    WaveChunk* ch = reinterpret_cast<WaveChunk*>((char*)stage + draw_bytes);
+    size_t ci = 0;
+    for (size_t di = 0; di < draws.size(); di++)
+      for (uint32_t t = 0; t < draws[di].tri_count; t += 64u) {
+        ch[ci].draw = (uint32_t)di;
+        ch[ci].first_tri = t;
+        ci++;
+      }
+  }
   P.draws = (const DrawDesc*)set.inputs.p;
   P.chunks = (const WaveChunk*)((const char*)set.inputs.p + draw_bytes);  // DrawDesc is 128 B: stays aligned
 
@@ -386,7 +401,25 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
       if (!ctx->tev[ts][k]) HIPCHK(hipEventCreate(&ctx->tev[ts][k]));
   }
   // inputs out of the staging buffer + zero the counters, class counters and tile_count (adjacent)
-  launch_prologue(stage, set.inputs.p, draw_bytes + chunk_bytes, P.counters, TILE_HEAD_BYTES + (size_t)P.n_tiles * 2 * sizeof(uint32_t), g);
+  launch_prologue(stage, set.inputs.p, flat_op ? 0 : draw_bytes + chunk_bytes, P.counters,
+                  TILE_HEAD_BYTES + (size_t)P.n_tiles * 2 * sizeof(uint32_t), g);
+  if (flat_op) {
+    FlattenParams F;
+    std::memset(&F, 0, sizeof(F));
+    F.objects = (const SvrRenderObject*)stage;
+    F.n_opaque = flat_op->n_opaque_obj;
+    F.n_transparent = flat_op->n_transparent_obj;
+    std::memcpy(F.viewproj, P.scene.viewproj, 64);
+    F.meshes = (const MeshEntry*)ctx->mesh_table.p;
+    F.materials = (const MatEntry*)ctx->mat_table.p;
+    F.keys = (unsigned long long*)set.flat.p;
+    F.draw_tris = (uint32_t*)((char*)set.flat.p + n_objects * 8);
+    F.chunk_base = F.draw_tris + n_objects;
+    F.draws = (DrawDesc*)set.inputs.p;
+    F.chunks = (WaveChunk*)((char*)set.inputs.p + draw_bytes);
+    F.counters = P.counters;
+    launch_flatten(F, g);
+  }
   const bool all_stages = ctx->kernel_timing >= 2;
   if (ts >= 0 && all_stages) HIPCHK(hipEventRecord(ctx->tev[ts][0], g));
   launch_setup(P, g);
@@ -421,6 +454,12 @@ void note_pass_stats(SvrContext* ctx, const FrameParams&, const Counters& c) {  
   ctx->stats.rasterized_fragments = c.rasterized;
   ctx->stats.shaded_fragments = c.shaded;
   ctx->stats.binned_triangles = c.binned;
+}
+
+void note_flatten_stats(SvrContext* ctx, const Counters& c) {  // device-flattened passes learn these late
+  ctx->stats.drawcall_count = (int32_t)c.flat_draws;
+  ctx->stats.triangle_count = (int32_t)c.flat_tris;
+  ctx->stats.culled_draws = c.flat_culled;
 }
 
 // ---------------------------------------------------------------- the operation log
@@ -469,7 +508,7 @@ int recover_from_overflow(SvrContext* ctx) {
         ctx->bin_cap = std::max<uint32_t>(ctx->bin_cap * 2u, need + need / 4u);
       }
       HIPCHK(hipMemsetAsync(ctx->d_poison, 0, sizeof(uint32_t), ctx->stream));
-      if (int e = submit_pass(ctx, op.P, op.draws, op.slot, op.seq, false)) return e;
+      if (int e = submit_pass(ctx, op.P, op.draws, op.slot, op.seq, false, op.P.flatten ? &op : nullptr)) return e;
       HIPCHK(hipStreamSynchronize(ctx->stream));
       HIPCHK(hipMemcpy(&c, ctx->last.counters, sizeof(Counters), hipMemcpyDeviceToHost));
       *ctx->h_failed_seq = 0;
@@ -480,6 +519,7 @@ int recover_from_overflow(SvrContext* ctx) {
       return fail(SVR_ERR_OVERFLOW, "a pass kept overflowing its internal queues after 12 replays");
     }
     if (op.P.instrument) note_pass_stats(ctx, op.P, c);
+    if (op.P.flatten) note_flatten_stats(ctx, c);
     ctx->replayed++;
   }
   HIPCHK(hipMemsetAsync(ctx->d_poison, 0, sizeof(uint32_t), ctx->stream));
@@ -517,6 +557,7 @@ int retire_ops(SvrContext* ctx, bool blocking) {
       return recover_from_overflow(ctx);
     }
     if (ctx->log[k].P.instrument) note_pass_stats(ctx, ctx->log[k].P, ctx->h_counters[slot]);
+    if (ctx->log[k].P.flatten) note_flatten_stats(ctx, ctx->h_counters[slot]);
     ctx->log.erase(ctx->log.begin(), ctx->log.begin() + (long)k + 1);
   }
   return SVR_OK;
@@ -549,18 +590,8 @@ int log_slot(SvrContext* ctx, int* slot) {
 int finish_pending(SvrContext* ctx) { return retire_ops(ctx, true); }  // the fence
 int poll_pending(SvrContext* ctx) { return retire_ops(ctx, false); }
 
-int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& draws) {
-  if (int e = poll_pending(ctx)) return e;
-  // sequence numbers + wave chunks
-  uint64_t n_tris64 = 0;
-  size_t n_chunks = 0;
-  for (DrawDesc& d : draws) {
-    d.tri_base = (uint32_t)n_tris64;
-    n_tris64 += d.tri_count;
-    n_chunks += (d.tri_count + 63u) / 64u;
-  }
+int fill_frame_params(SvrContext* ctx, const SvrSceneData* scene, uint64_t n_tris64, size_t n_chunks, FrameParams& P) {
   if (n_tris64 >= 0x7ffffff0ull) return fail(SVR_ERR_UNSUPPORTED, "more than 2^31 triangles in one pass");
-  FrameParams P;
   std::memset(&P, 0, sizeof(P));
   P.color = ctx->color;
   P.depth = ctx->depth;
@@ -587,6 +618,21 @@ int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& 
     P.tile_cycles = (uint32_t*)ctx->d_tile_cycles.p;
   }
   if (scene) P.scene = *scene;
+  return SVR_OK;
+}
+
+int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& draws) {
+  if (int e = poll_pending(ctx)) return e;
+  // sequence numbers + wave chunks
+  uint64_t n_tris64 = 0;
+  size_t n_chunks = 0;
+  for (DrawDesc& d : draws) {
+    d.tri_base = (uint32_t)n_tris64;
+    n_tris64 += d.tri_count;
+    n_chunks += (d.tri_count + 63u) / 64u;
+  }
+  FrameParams P;
+  if (int e = fill_frame_params(ctx, scene, n_tris64, n_chunks, P)) return e;
   int slot = 0;
   if (int e = log_slot(ctx, &slot)) return e;
   ctx->log.emplace_back();
@@ -599,6 +645,61 @@ int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& 
   op.draws.swap(draws);
   std::memset(&ctx->h_counters[slot], 0, sizeof(Counters));
   if (int e = submit_pass(ctx, op.P, op.draws, slot, op.seq, !(ctx->tuning & TUNE_NO_PIPELINE))) {
+    ctx->log.pop_back();
+    return e;
+  }
+  return SVR_OK;
+}
+
+// (re)upload the handle -> resource tables the device flatten pass reads
+int upload_flatten_tables(SvrContext* ctx) {
+  if (ctx->mesh_table_n == ctx->meshes.size() && ctx->mat_table_n == ctx->materials.size()) return SVR_OK;
+  if (int e = finish_pending(ctx)) return e;  // a pass in flight may be reading the old tables
+  std::vector<MeshEntry> me(ctx->meshes.size());
+  for (size_t i = 0; i < me.size(); i++) {
+    me[i].vtx = ctx->meshes[i].vtx;
+    me[i].idx = ctx->meshes[i].idx;
+  }
+  std::vector<MatEntry> ma(ctx->materials.size());
+  for (size_t i = 0; i < ma.size(); i++) {
+    std::memset(&ma[i], 0, sizeof(MatEntry));
+    std::memcpy(ma[i].cf, ctx->materials[i].cf, 16);
+    ma[i].pass = (uint32_t)ctx->materials[i].pass;
+  }
+  if (int e = ctx->mesh_table.ensure(std::max<size_t>(me.size() * sizeof(MeshEntry), 256))) return e;
+  if (int e = ctx->mat_table.ensure(std::max<size_t>(ma.size() * sizeof(MatEntry), 256))) return e;
+  if (!me.empty()) HIPCHK(hipMemcpy(ctx->mesh_table.p, me.data(), me.size() * sizeof(MeshEntry), hipMemcpyHostToDevice));
+  if (!ma.empty()) HIPCHK(hipMemcpy(ctx->mat_table.p, ma.data(), ma.size() * sizeof(MatEntry), hipMemcpyHostToDevice));
+  ctx->mesh_table_n = me.size();
+  ctx->mat_table_n = ma.size();
+  return SVR_OK;
+}
+
+// draw_geometry with cull, sort and the draw records left to the device (k_flatten.hip): the host only
+// validates, sums the upper bounds that size buffers and grids, and hands the objects over.
+int run_pass_flatten(SvrContext* ctx, const SvrSceneData* scene, const SvrRenderObject* opaque, size_t n_opaque,
+                     const SvrRenderObject* transparent, size_t n_transparent, uint64_t tris_max, size_t chunks_max) {
+  if (int e = poll_pending(ctx)) return e;
+  if (int e = upload_flatten_tables(ctx)) return e;
+  FrameParams P;
+  if (int e = fill_frame_params(ctx, scene, tris_max, chunks_max, P)) return e;
+  P.flatten = 1u;
+  int slot = 0;
+  if (int e = log_slot(ctx, &slot)) return e;
+  ctx->log.emplace_back();
+  SvrContext::LoggedOp& op = ctx->log.back();
+  op.is_pass = true;
+  op.seq = ctx->next_seq++;
+  if (ctx->next_seq == 0) ctx->next_seq = 1;
+  op.slot = slot;
+  op.P = P;
+  op.objects.reserve(n_opaque + n_transparent);
+  op.objects.insert(op.objects.end(), opaque, opaque + n_opaque);
+  op.objects.insert(op.objects.end(), transparent, transparent + n_transparent);
+  op.n_opaque_obj = (uint32_t)n_opaque;
+  op.n_transparent_obj = (uint32_t)n_transparent;
+  std::memset(&ctx->h_counters[slot], 0, sizeof(Counters));
+  if (int e = submit_pass(ctx, op.P, op.draws, slot, op.seq, !(ctx->tuning & TUNE_NO_PIPELINE), &op)) {
     ctx->log.pop_back();
     return e;
   }
@@ -676,9 +777,9 @@ void svr_destroy(SvrContext* ctx) {
   }
   for (auto& im : ctx->images)
     if (im.base) (void)hipFree(im.base);
-  DevBuf* bufs[] = {&ctx->tex_table, &ctx->d_cvt, &ctx->d_trace, &ctx->d_tile_cycles};
+  DevBuf* bufs[] = {&ctx->tex_table, &ctx->d_cvt, &ctx->d_trace, &ctx->d_tile_cycles, &ctx->mesh_table, &ctx->mat_table};
   for (auto& set : ctx->sets) {
-    DevBuf* sb[] = {&set.inputs, &set.recs, &set.clipq, &set.bigq, &set.tiles, &set.bins, &set.pairs};
+    DevBuf* sb[] = {&set.inputs, &set.recs, &set.clipq, &set.bigq, &set.tiles, &set.bins, &set.pairs, &set.flat};
     for (DevBuf* b : sb) b->release();
     if (set.ev_bin) (void)hipEventDestroy(set.ev_bin);
   }
@@ -1016,6 +1117,26 @@ int svr_draw_geometry(SvrContext* ctx, const SvrSceneData* scene, const SvrRende
     if (int e = validate_object(ctx, transparent[i], true)) return e;
   if (ctx->tex_slots != ctx->materials.size() + 1)
     if (int e = upload_tex_table(ctx, nullptr)) return e;
+  // Many objects: cull, sort and the per-object records run on the device (k_flatten.hip).  The three
+  // counts of the stats then only exist after the pass (svr_get_stats); out_stats gets what the host knows.
+  const size_t n_objects = n_opaque + n_transparent;
+  const bool fits = n_objects <= 16384 && ctx->meshes.size() < (1u << 20) && ctx->materials.size() < (1u << 20);
+  if (fits && n_objects > 0 && (ctx->device_flatten == 1 || (ctx->device_flatten == 0 && n_objects >= 2048))) {
+    uint64_t tris_max = 0;
+    size_t chunks_max = 0;
+    for (size_t i = 0; i < n_objects; i++) {
+      uint32_t t = (i < n_opaque ? opaque[i] : transparent[i - n_opaque]).index_count / 3u;
+      tris_max += t;
+      chunks_max += (t + 63u) / 64u;
+    }
+    SvrStats st{};
+    int e = run_pass_flatten(ctx, scene, opaque, n_opaque, transparent, n_transparent, tris_max, chunks_max);
+    auto t1 = std::chrono::steady_clock::now();
+    st.mesh_draw_time = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    ctx->stats = st;
+    if (out_stats) *out_stats = st;
+    return e;
+  }
   // cull: opaque only (src/vk_engine.cpp:1361-1367)
   std::vector<uint32_t> order;
   order.reserve(n_opaque);
@@ -1155,6 +1276,11 @@ int svr_set_option(SvrContext* ctx, int option, int64_t value) {
   }
   if (option == SVR_OPT_TUNING) {
     ctx->tuning = (uint32_t)value;
+    return SVR_OK;
+  }
+  if (option == SVR_OPT_DEVICE_FLATTEN) {
+    if (value < 0 || value > 2) return fail(SVR_ERR_INVALID_ARGUMENT, "SVR_OPT_DEVICE_FLATTEN: 0 auto, 1 always, 2 never");
+    ctx->device_flatten = (int)value;
     return SVR_OK;
   }
   if (option == SVR_OPT_QUEUE_CAPS) {

@@ -112,7 +112,25 @@ struct Counters {
   uint32_t n_pairs;        // (bin, record) pairs appended so far (keeps counting past pair capacity)
   uint32_t n_pairs_setup;  // n_pairs when the setup kernel had finished (snapshot taken by clip_kernel)
   uint32_t pad32;
-  unsigned long long pad[1];  // 64 bytes: the counters head the tile-counter allocation (one memset)
+  unsigned long long pad[1];
+  // device flatten (k_flatten.hip): what the host only knows upper bounds of
+  uint32_t flat_draws;     // draws after culling (visible opaque + transparent)
+  uint32_t flat_tris;      // their triangles
+  uint32_t flat_chunks;    // their wave chunks: the setup kernel's real grid
+  uint32_t flat_culled;    // opaque objects rejected by is_visible
+  unsigned long long pad2[2];  // 96 bytes: the counters head the tile-counter allocation (zeroed by the prologue)
+};
+static_assert(sizeof(Counters) == 96, "Counters layout");
+
+// resource tables of the device flatten pass (handle - 1 indexes them)
+struct MeshEntry {
+  const SvrVertex* vtx;
+  const uint32_t* idx;
+};
+struct MatEntry {
+  float cf[4];
+  uint32_t pass;
+  uint32_t pad[3];
 };
 
 struct FrameParams {
@@ -139,6 +157,7 @@ struct FrameParams {
   Counters* host_counters;        // pinned host copy, written by report_kernel behind the tile kernel
   uint32_t* host_failed_seq;      // pinned: op_seq of the first pass that overflowed since the last recovery (0 = none)
   uint32_t op_seq;                // this pass's number in the context's operation log (never 0)
+  uint32_t flatten;               // 1: draws/chunks were built on the device; n_tris / n_chunks are upper bounds
   uint32_t* poison;               // sticky per-context flag: an earlier pass overflowed, target writes are void
   uint2* pairs;                   // [bin_cap] (bin, record): what binning scatters, in emission order
   uint32_t* pair_slot;            // [bin_cap] position of the pair inside its bin
@@ -155,6 +174,21 @@ struct FrameParams {
   uint32_t tuning;                // SVR_OPT_TUNING bits (A/B switches for benchmarking, default 0)
   uint32_t pad_t;
   SvrSceneData scene;
+};
+
+// k_flatten.hip: cull + sort + per-object draw records on the device
+struct FlattenParams {
+  const SvrRenderObject* objects;  // pinned host memory: opaque list, then the transparent list
+  uint32_t n_opaque, n_transparent;
+  float viewproj[16];
+  const MeshEntry* meshes;
+  const MatEntry* materials;
+  unsigned long long* keys;  // [n_opaque]
+  uint32_t* draw_tris;       // [n_opaque + n_transparent]
+  uint32_t* chunk_base;      // [n_opaque + n_transparent]
+  DrawDesc* draws;
+  WaveChunk* chunks;
+  Counters* counters;
 };
 
 // ------------------------------------------------------------------------------------------------

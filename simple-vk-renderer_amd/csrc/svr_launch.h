@@ -12,6 +12,8 @@ void launch_clip(const FrameParams& P, hipStream_t s);
 void launch_mesh_vert(const SvrVertex* vtx, uint32_t first, uint32_t n, const float* world16,
                       const float* viewproj16, const float* color_factors4, float* out_clip,
                       float* out_varyings, hipStream_t s);
+// k_flatten.hip
+void launch_flatten(const FlattenParams& F, hipStream_t s);
 // k_bin.hip
 void launch_bin_count(const FrameParams& P, hipStream_t s);
 void launch_bin_scan(const FrameParams& P, hipStream_t s);

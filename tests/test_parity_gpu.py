@@ -180,6 +180,24 @@ def test_identity_blit_writes_the_scissor_rows(hip):
     r.close()
 
 
+def test_device_flatten_matches_the_host_path(hip, oracle):
+    """SVR_OPT_DEVICE_FLATTEN = 1: is_visible, the sort and the draw records on the device (k_flatten.hip).
+    Frames, fragment counts and the three late stats equal the oracle's (whose host loop is the
+    reference's), for the plain scene, the 16-instance grid (5408 objects: above the automatic
+    threshold too), cameras inside geometry, and with queue overflows replayed."""
+    cases = [dict(lod=4, tex_size=64), dict(lod=8, tex_size=32, camera=S.config5_camera(), instances=S.config5_instances()),
+             dict(lod=4, tex_size=64, camera=((2.5, 1.0, -5.5), 0.2, 1.0)), dict(lod=4, tex_size=64, camera=((54.5, 15.5, 0.0), -1.2, 4.6))]
+    for k, kw in enumerate(cases):
+        b = T.render_sponza(oracle, 320, 180, instrument=True, threads=8, **kw)
+        for mode in (1, 0):
+            a = T.render_sponza(hip, 320, 180, instrument=True, device_flatten=mode, **kw)
+            assert_same(a, b, f"device flatten case {k} mode {mode}")
+    b = T.render_sponza(oracle, 320, 180, lod=4, tex_size=64, instrument=True)
+    a = T.render_sponza(hip, 320, 180, lod=4, tex_size=64, instrument=True, device_flatten=1, queue_caps=64)
+    assert_same(a, b, "device flatten with replays")
+    assert a["stats"].replayed_passes >= 1
+
+
 def test_rgba8_target(hip, oracle):
     a, b = both(T.render_sponza, hip, oracle, 320, 180, lod=8, tex_size=64, color_format=A.COLOR_RGBA8, instrument=True)
     assert_same(a, b, "config3 rgba8")

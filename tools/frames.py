@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--instances", type=int, default=1)
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--hist", action="store_true")
+    ap.add_argument("--flatten", type=int, default=0, help="SVR_OPT_DEVICE_FLATTEN: 0 auto, 1 device, 2 host")
     ap.add_argument("--ab", default="", help="comma list of SVR_OPT_TUNING masks to time interleaved, e.g. 0,1")
     args = ap.parse_args()
     pkg = g.load_package()
@@ -37,6 +38,7 @@ def main():
     opaque, transparent = sc.render_objects(handles, instance_transforms=inst)
     pos, pitch, yaw = S.config5_camera() if args.instances == 16 else S.config3_camera()
     scene = S.scene_data_struct(pos, pitch, yaw, args.width, args.height)
+    r.set_option(A.OPT_DEVICE_FLATTEN, args.flatten)
     r.set_option(A.OPT_KERNEL_TIMING, 2)
     for _ in range(3):
         r.clear_color((1, 1, 1, 1))
