@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void setup_kernel(FrameParams P) {
         ScreenV s0 = to_screen(v0.clip, hw, hh), s1 = to_screen(v1.clip, hw, hh), s2 = to_screen(v2.clip, hw, hh);
         if (s0.ok && s1.ok && s2.ok) {
           to_clip = false;
-          ok = setup_triangle(P, &v0, &v1, &v2, s0, s1, s2, (seq + 1u) << 1, d.flags, P.tex[d.tex], piece, &g);
+          ok = setup_triangle(P, &v0, &v1, &v2, s0, s1, s2, make_key(seq, d.flags, P.tex[d.tex], false), d.flags, P.tex[d.tex], piece, &g);
         }
       }
     }
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64) void clip_kernel(FrameParams P) {
     int np = clip_polygon(poly, 3);
     if (np < 3) continue;
     // The fan's records are one contiguous block, and the parent's (invalid) main slot links to it:
-    // the tile kernel's visibility pass keeps only (depth, key) per pixel and (key >> 1) - 1 names the main
+    // the tile kernel's visibility pass keeps only (depth, key) per pixel and (key >> 2) - 1 names the main
     // slot, so shading finds a clipped parent's covering piece through this link.
     uint32_t want = (uint32_t)(np - 2);
     uint32_t first = atomicAdd(&P.counters->n_extra, want);
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void clip_kernel(FrameParams P) {
       if (!(s0.ok && s1.ok && s2.ok)) continue;
       if (!(poly[0].clip[3] > 0.0f && poly[i].clip[3] > 0.0f && poly[i + 1].clip[3] > 0.0f)) continue;
       uint4 piece[16];
-      if (!setup_triangle(P, &poly[0], &poly[i], &poly[i + 1], s0, s1, s2, ((seq + 1u) << 1) | 1u, d.flags, P.tex[d.tex], piece, nullptr)) continue;
+      if (!setup_triangle(P, &poly[0], &poly[i], &poly[i + 1], s0, s1, s2, make_key(seq, d.flags, P.tex[d.tex], true), d.flags, P.tex[d.tex], piece, nullptr)) continue;
       uint4* dst = reinterpret_cast<uint4*>(P.recs + P.n_tris + first + used);
 #pragma unroll
       for (int k = 0; k < 16; k++) dst[k] = piece[k];

@@ -122,7 +122,9 @@ __device__ __forceinline__ float interp3(float a0, float da1, float da2, float b
 // whole 8x8 block runs whole quads of one triangle — with ~40 triangles per tile almost no block
 // qualifies, -1 %; the 4-pixel loop is VALU-issue-bound at ~500 instructions per pixel, SQ counters
 // in DESIGN.md.)
-template <bool TRACE>
+// COMMON: the caller knows (key bit 1) that this is mesh.frag with a LINEAR/LINEAR/MIPMAP_LINEAR sampler:
+// pipeline kind, filter and mip-mode selections fold away (same arithmetic on the surviving path).
+template <bool TRACE, bool COMMON = false>
 __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec, int px, int py, float* trace) {
   const TriRec* tr = P.recs + rec;
   const uint4* q4 = reinterpret_cast<const uint4*>(tr);
@@ -158,7 +160,7 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
   float b1 = (float)e1 * inv_area, b2 = (float)e2 * inv_area;
   float q0 = s0.x, dq1 = s0.y, dq2 = s0.z;
   float r = 1.0f / fmaf(b2, dq2, fmaf(b1, dq1, q0));
-  uint32_t kind = (flags >> F_KIND_SHIFT) & 3u;
+  const uint32_t kind = COMMON ? (uint32_t)PIPE_MESH : ((flags >> F_KIND_SHIFT) & 3u);
   float cr = interp3(s1.z, s3.z, s5.z, b1, b2, r);
   float cg = interp3(s1.w, s3.w, s5.w, b1, b2, r);
   float cb = interp3(s2.x, s4.x, s6.x, b1, b2, r);
@@ -181,9 +183,9 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
   float nx_ = dudy * W0, ny_ = dvdy * H0;
   float rho2 = fmaxf(fmaf(mx, mx, my * my), fmaf(nx_, nx_, ny_ * ny_));
   float lambda = fminf(fmaxf(lod_from_rho2(rho2), t.min_lod), t.max_lod);
-  bool linear = ((lambda <= 0.0f) ? (t.filters & 1u) : ((t.filters >> 1) & 1u)) != 0u;
+  const bool linear = COMMON ? true : (((lambda <= 0.0f) ? (t.filters & 1u) : ((t.filters >> 1) & 1u)) != 0u);
   int q = (int)t.levels - 1;
-  bool mip_linear = ((t.filters >> 2) & 1u) != 0u;
+  const bool mip_linear = COMMON ? true : (((t.filters >> 2) & 1u) != 0u);
   int dn = min(max((int)ceilf(lambda + 0.5f) - 1, 0), q);
   float lc = fminf(fmaxf(lambda, 0.0f), (float)q);
   float fl = floorf(lc);
@@ -212,7 +214,7 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
   tx.z = lerpf(bilerp(h00, h10, h01, h11, 2, th.alpha, th.beta), bilerp(l00, l10, l01, l11, 2, tl.alpha, tl.beta), delta);
   tx.w = 1.0f;
   if (TRACE) {  // slots shared with the oracle's trace (tests/tools only)
-    trace[0] = (float)(hdr.z >> 1); trace[1] = b1; trace[2] = b2; trace[3] = r; trace[4] = u; trace[5] = v;
+    trace[0] = (float)(hdr.z >> 2); trace[1] = b1; trace[2] = b2; trace[3] = r; trace[4] = u; trace[5] = v;
     trace[6] = dudx; trace[7] = dvdx; trace[8] = dudy; trace[9] = dvdy; trace[10] = lambda;
     trace[11] = tx.x; trace[12] = tx.y; trace[13] = tx.z;
     trace[26] = hb1; trace[27] = hb2; trace[28] = vb1; trace[29] = vb2; trace[30] = hr; trace[31] = vr;
@@ -446,7 +448,7 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
   }
 }
 
-// (key >> 1) - 1 is the main record slot, and for keys with bit 0 clear that is the record.  Bit 0 set:
+// (key >> 2) - 1 is the main record slot, and for keys with bit 0 clear that is the record.  Bit 0 set:
 // the triangle went through the clipper, its slot is an invalid record that links to the contiguous
 // block of its pieces (k_geometry.hip clip_kernel); exactly one of them covers the pixel (they
 // partition the parent under the top-left rule).  The flag keeps this dependent load out of the
@@ -739,7 +741,7 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
       if ((uint32_t)v != 0u) {
         zbits[k] = (uint32_t)(v >> 32);
         keys[k] = (uint32_t)v;
-        uint32_t main_slot = ((uint32_t)v >> 1) - 1u;
+        uint32_t main_slot = ((uint32_t)v >> 2) - 1u;
         recs[k] = ((uint32_t)v & 1u) ? resolve_record(P, main_slot, px, py) : main_slot;
       }
     }
@@ -754,8 +756,16 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
   for (int k = 0; k < 4; k++) {
     dirty[k] = recs[k] != NO_REC;
     enc[k] = enc_t();
-    if (dirty[k]) {
-      int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
+    int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
+    if (__all(!dirty[k] || (keys[k] & 2u))) {  // every shaded pixel of the wave is the common case
+      if (dirty[k]) {
+        enc[k] = CD::encode(shade_pixel<false, true>(P, recs[k], px, py, nullptr));
+        if (INSTR) {
+          n_shaded++;
+          if (P.trace_buf && px == P.trace_x && py == P.trace_y) (void)shade_pixel<true>(P, recs[k], px, py, P.trace_buf);
+        }
+      }
+    } else if (dirty[k]) {
       enc[k] = CD::encode(shade_pixel<false>(P, recs[k], px, py, nullptr));
       if (INSTR) {
         n_shaded++;

@@ -591,7 +591,7 @@ int finish_pending(SvrContext* ctx) { return retire_ops(ctx, true); }  // the fe
 int poll_pending(SvrContext* ctx) { return retire_ops(ctx, false); }
 
 int fill_frame_params(SvrContext* ctx, const SvrSceneData* scene, uint64_t n_tris64, size_t n_chunks, FrameParams& P) {
-  if (n_tris64 >= 0x7ffffff0ull) return fail(SVR_ERR_UNSUPPORTED, "more than 2^31 triangles in one pass");
+  if (n_tris64 >= 0x3ffffff0ull) return fail(SVR_ERR_UNSUPPORTED, "more than 2^30 triangles in one pass");
   std::memset(&P, 0, sizeof(P));
   P.color = ctx->color;
   P.depth = ctx->depth;

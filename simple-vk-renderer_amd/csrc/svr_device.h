@@ -78,7 +78,7 @@ __host__ __device__ inline uint32_t mip_offset(uint32_t lw, uint32_t lh, uint32_
 // VALU instruction per ~4 cycles, which is also the cost of a 16-lane/clk v_fma_f64.)
 struct TriRec {
   int16_t minx, miny, maxx, maxy;  // inclusive pixel bbox clamped to the scissor; minx>maxx = invalid
-  uint32_t key;                    // (submission sequence number + 1) << 1 | came-through-the-clipper
+  uint32_t key;                    // make_key(): (submission sequence number + 1) << 2 | common-case shading << 1 | came-through-the-clipper
   uint32_t flags;
   float z0, dz1, dz2, inv_area;
   double A[3], B[3], C[3];
@@ -311,6 +311,16 @@ __device__ __forceinline__ void store_invalid(TriRec* rec) {
 
 // C4..C6: snap, orient, edge functions, attribute deltas.  Returns false when the triangle is
 // dropped (zero area or no pixel centre inside the scissor).
+// The per-triangle key the tile kernel resolves visibility and order with.  Two flag bits ride below the
+// submission number (they cannot change an order between different triangles):
+//   bit 0  the record came through the clipper: the main slot only links to the pieces
+//   bit 1  the fragment stage is the common case — mesh.frag with a LINEAR/LINEAR/MIPMAP_LINEAR sampler —
+//          for which the tile kernel has a specialised instance (a wave whose pixels all carry it takes it)
+__device__ __forceinline__ uint32_t make_key(uint32_t seq, uint32_t draw_flags, const TexBinding& tex, bool clipped) {
+  bool common = ((draw_flags >> F_KIND_SHIFT) & 3u) == PIPE_MESH && (tex.info >> 24) == 7u;
+  return ((seq + 1u) << 2) | (common ? 2u : 0u) | (clipped ? 1u : 0u);
+}
+
 // what binning needs of a set-up triangle, still in registers
 struct TriGeom {
   int minx, miny, maxx, maxy;
