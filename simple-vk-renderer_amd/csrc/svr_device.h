@@ -61,12 +61,16 @@ struct TexBinding {
 };
 static_assert(sizeof(TexBinding) == 32, "TexBinding layout");
 
+// = sum over k < level of 4 * 2^max(lw-k,0) * 2^max(lh-k,0), for level <= max(lw, lh), without a loop
+// (the fragment stage evaluates it twice per pixel).  While both extents halve the sum is
+// 2^(lw+lh+4-2l) * (4^l - 1)/3, and (4^l - 1)/3 is the bit pattern 0101..01 with l ones; past the smaller
+// extent only the larger one halves: a geometric tail of 4 * 2^(b-k).
 __host__ __device__ inline uint32_t mip_offset(uint32_t lw, uint32_t lh, uint32_t level) {
-  uint32_t off = 0;
-  for (uint32_t k = 0; k < level; k++) {
-    uint32_t a = lw > k ? lw - k : 0u, b = lh > k ? lh - k : 0u;
-    off += 4u << (a + b);
-  }
+  const uint32_t a = lw < lh ? lw : lh, b = lw < lh ? lh : lw;
+  const uint32_t l1 = level < a ? level : a;
+  const uint32_t ones = l1 ? (0x55555555u >> (32u - 2u * l1)) : 0u;
+  uint32_t off = ones << ((lw + lh + 4u - 2u * l1) & 31u);
+  if (level > a) off += 4u * ((1u << (b - a + 1u)) - (1u << (b - level + 1u)));
   return off;
 }
 
