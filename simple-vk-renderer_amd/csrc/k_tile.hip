@@ -101,10 +101,12 @@ __device__ __forceinline__ Taps level_taps(const TexD& t, uint32_t level, bool l
   if (j0 < 0) j0 += hl;
   if (j0 >= hl) j0 -= hl;
   if (j1 >= hl) j1 -= hl;
-  tp.o00 = base + (uint32_t)(j0 * wl + i0) * 4u;
-  tp.o10 = base + (uint32_t)(j0 * wl + i1) * 4u;
-  tp.o01 = base + (uint32_t)(j1 * wl + i0) * 4u;
-  tp.o11 = base + (uint32_t)(j1 * wl + i1) * 4u;
+  // rows and extents are below 2^14: the 24-bit multiply is full rate where v_mul_lo_u32 is quarter rate
+  const uint32_t r0 = __umul24((uint32_t)j0, (uint32_t)wl), r1 = __umul24((uint32_t)j1, (uint32_t)wl);
+  tp.o00 = base + (r0 + (uint32_t)i0) * 4u;
+  tp.o10 = base + (r0 + (uint32_t)i1) * 4u;
+  tp.o01 = base + (r1 + (uint32_t)i0) * 4u;
+  tp.o11 = base + (r1 + (uint32_t)i1) * 4u;
   return tp;
 }
 __device__ __forceinline__ float chan(uint32_t t, int c) { return (float)((t >> (8 * c)) & 0xffu) * kInv255; }
@@ -198,10 +200,12 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
   uint32_t h00 = *reinterpret_cast<const uint32_t*>(tb + th.o00), h10 = *reinterpret_cast<const uint32_t*>(tb + th.o10);
   uint32_t h01 = *reinterpret_cast<const uint32_t*>(tb + th.o01), h11 = *reinterpret_cast<const uint32_t*>(tb + th.o11);
   // The second level only matters where delta != 0 (lerp(H, L, 0) == H exactly): magnified and
-  // NEAREST-mip pixels skip its four taps when no lane of the wave needs them.
+  // NEAREST-mip pixels skip its four taps when no lane of the wave needs them.  Its loads are issued
+  // before anything consumes the first level's texels, so both batches are in flight together.
+  const bool two_levels = __any(delta != 0.0f);
   Taps tl = th;
-  uint32_t l00 = h00, l10 = h10, l01 = h01, l11 = h11;
-  if (__any(delta != 0.0f)) {
+  uint32_t l00 = 0, l10 = 0, l01 = 0, l11 = 0;
+  if (two_levels) {
     tl = level_taps(t, (uint32_t)dlo, linear, us, vs);
     l00 = *reinterpret_cast<const uint32_t*>(tb + tl.o00);
     l10 = *reinterpret_cast<const uint32_t*>(tb + tl.o10);
@@ -209,10 +213,15 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
     l11 = *reinterpret_cast<const uint32_t*>(tb + tl.o11);
   }
   float4 tx;
-  tx.x = lerpf(bilerp(h00, h10, h01, h11, 0, th.alpha, th.beta), bilerp(l00, l10, l01, l11, 0, tl.alpha, tl.beta), delta);
-  tx.y = lerpf(bilerp(h00, h10, h01, h11, 1, th.alpha, th.beta), bilerp(l00, l10, l01, l11, 1, tl.alpha, tl.beta), delta);
-  tx.z = lerpf(bilerp(h00, h10, h01, h11, 2, th.alpha, th.beta), bilerp(l00, l10, l01, l11, 2, tl.alpha, tl.beta), delta);
+  tx.x = bilerp(h00, h10, h01, h11, 0, th.alpha, th.beta);
+  tx.y = bilerp(h00, h10, h01, h11, 1, th.alpha, th.beta);
+  tx.z = bilerp(h00, h10, h01, h11, 2, th.alpha, th.beta);
   tx.w = 1.0f;
+  if (two_levels) {
+    tx.x = lerpf(tx.x, bilerp(l00, l10, l01, l11, 0, tl.alpha, tl.beta), delta);
+    tx.y = lerpf(tx.y, bilerp(l00, l10, l01, l11, 1, tl.alpha, tl.beta), delta);
+    tx.z = lerpf(tx.z, bilerp(l00, l10, l01, l11, 2, tl.alpha, tl.beta), delta);
+  }
   if (TRACE) {  // slots shared with the oracle's trace (tests/tools only)
     trace[0] = (float)(hdr.z >> 2); trace[1] = b1; trace[2] = b2; trace[3] = r; trace[4] = u; trace[5] = v;
     trace[6] = dudx; trace[7] = dvdx; trace[8] = dudy; trace[9] = dvdy; trace[10] = lambda;
@@ -220,7 +229,8 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
     trace[26] = hb1; trace[27] = hb2; trace[28] = vb1; trace[29] = vb2; trace[30] = hr; trace[31] = vr;
   }
   if (kind == PIPE_TEX_IMAGE) {  // shaders/tex_image.frag:10-12 — the only consumer of texture alpha
-    tx.w = lerpf(bilerp(h00, h10, h01, h11, 3, th.alpha, th.beta), bilerp(l00, l10, l01, l11, 3, tl.alpha, tl.beta), delta);
+    tx.w = bilerp(h00, h10, h01, h11, 3, th.alpha, th.beta);
+    if (two_levels) tx.w = lerpf(tx.w, bilerp(l00, l10, l01, l11, 3, tl.alpha, tl.beta), delta);
     return tx;
   }
   // shaders/mesh.frag:12-19
