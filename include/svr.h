@@ -178,7 +178,12 @@ int svr_write_material(SvrContext* ctx, int pass, const float color_factors[4],
 
 /* Result of draw_background (src/vk_engine.cpp:1341-1355, gradient_color.comp with
  * data1 == data2): fill the colour target with one RGBA value.  The fill covers the rows of the
- * current scissor (all rows unless the multi-GPU path narrowed it: a rank only owns its band). */
+ * current scissor (all rows unless the multi-GPU path narrowed it: a rank only owns its band).
+ * The fill may be deferred into the pass that follows (which then writes the clear value to the pixels
+ * it does not cover: loadOp CLEAR instead of a clear command); every other svr_* call that reads, writes,
+ * exposes or re-targets the colour target runs it first, so the library's own results never differ.
+ * Only foreign work on a caller-bound target between the clear and the next svr_* call would see the
+ * old contents: call svr_sync first, or set SVR_OPT_TUNING bit 2. */
 int svr_clear_color(SvrContext* ctx, const float rgba[4]);
 
 /* VulkanEngine::draw_background (src/vk_engine.cpp:1341-1355): run one of the two ComputeEffects of
@@ -249,7 +254,8 @@ int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint
  * SVR_OPT_TUNING: bit mask that switches individual optimisations OFF (A/B timing inside one
  * process; results are identical either way).  bit0: tile kernel walks tiles row-major instead of
  * heaviest-first.  bit1: geometry + binning run on the caller's stream instead of overlapping the
- * previous pass's tile stage on an internal stream.
+ * previous pass's tile stage on an internal stream.  bit2: svr_clear_color runs at once instead of riding in
+ * the next pass.
  * SVR_OPT_DEVICE_FLATTEN: where svr_draw_geometry's host half runs — is_visible, the sort and the
  * per-object draw records (src/vk_engine.cpp:1361-1378, 1412-1457).  0 (default): on the device from
  * 2048 objects up, on the host below; 1: always on the device; 2: always on the host.  Same frames

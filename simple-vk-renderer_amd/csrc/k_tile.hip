@@ -784,6 +784,17 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
     }
   }
 
+  if (P.lazy_clear) {  // the deferred svr_clear_color: every pixel the opaque geometry left untouched
+    enc_t cv;
+    if constexpr (sizeof(enc_t) == 8) cv = enc_t(make_uint2(P.clear_lo, P.clear_hi));
+    else cv = enc_t(P.clear_lo);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (!dirty[k] && pix_ok[k]) {
+        enc[k] = cv;
+        dirty[k] = true;
+      }
+  }
   if (stamps) stamp[2] = clock64();
   // ---- phase C: transparent fragments in submission order
   if (n_tr && n_tr <= SORT_CAP) {

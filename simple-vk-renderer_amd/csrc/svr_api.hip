@@ -160,6 +160,14 @@ struct SvrContext {
   hipEvent_t op_done[MAX_OPS] = {};
   int op_pos = 0;
   uint32_t replayed = 0;         // passes re-run by recover_from_overflow
+  // svr_clear_color deferred into the next pass (the attachment's loadOp CLEAR): see flush_clear
+  struct PendingClear {
+    bool valid = false;
+    void* target = nullptr;
+    uint32_t y0 = 0, rows = 0;
+    int fmt = 0;
+    uint64_t packed = 0;
+  } pending_clear;
   uint32_t next_seq = 1;
   uint32_t* h_failed_seq = nullptr;  // pinned; written by the tile kernel of the first failing pass
   uint32_t* d_poison = nullptr;  // sticky device flag: a pass overflowed, later target writes are void
@@ -474,6 +482,7 @@ void note_flatten_stats(SvrContext* ctx, const Counters& c) {  // device-flatten
 // replayed_passes tells such a caller that a replay happened — see dist.py.)
 int log_slot(SvrContext* ctx, int* slot);
 int retire_ops(SvrContext* ctx, bool blocking);
+int flush_clear(SvrContext* ctx);
 
 int submit_clear(SvrContext* ctx, const SvrContext::LoggedOp& op) {  // every logged operation that is not a pass
   if (op.fill_kind == 0)
@@ -587,7 +596,33 @@ int log_slot(SvrContext* ctx, int* slot) {
   return SVR_OK;
 }
 
-int finish_pending(SvrContext* ctx) { return retire_ops(ctx, true); }  // the fence
+// A clear of whole scissor rows is not run when it is asked for: the pass that follows writes every
+// pixel of those rows anyway (its tile grid covers the scissor), so it takes the clear value for the
+// pixels it does not cover and the separate 8-bytes-per-pixel fill disappears — what a Vulkan renderer
+// gets from loadOp = CLEAR instead of a clear command.  Anything else that touches or exposes the
+// target first (another operation, a read-back, a fence, a change of targets) runs the clear as its
+// own kernel here.  SVR_OPT_TUNING bit 2 turns the deferral off.
+int flush_clear(SvrContext* ctx) {
+  if (!ctx->pending_clear.valid) return SVR_OK;
+  const SvrContext::PendingClear pc = ctx->pending_clear;
+  ctx->pending_clear.valid = false;
+  size_t px_bytes = pc.fmt == SVR_COLOR_RGBA16F ? 8 : 4;
+  int slot = 0;
+  if (int e = log_slot(ctx, &slot)) return e;
+  ctx->log.emplace_back();
+  SvrContext::LoggedOp& op = ctx->log.back();
+  op.slot = slot;
+  op.clear_rows = (char*)pc.target + (size_t)pc.y0 * ctx->W * px_bytes;
+  op.clear_pixels = ctx->W * pc.rows;
+  op.clear_fmt = pc.fmt;
+  op.clear_packed = pc.packed;
+  return submit_clear(ctx, op);
+}
+
+int finish_pending(SvrContext* ctx) {  // the fence
+  if (int e = flush_clear(ctx)) return e;
+  return retire_ops(ctx, true);
+}
 int poll_pending(SvrContext* ctx) { return retire_ops(ctx, false); }
 
 int fill_frame_params(SvrContext* ctx, const SvrSceneData* scene, uint64_t n_tris64, size_t n_chunks, FrameParams& P) {
@@ -618,6 +653,17 @@ int fill_frame_params(SvrContext* ctx, const SvrSceneData* scene, uint64_t n_tri
     P.tile_cycles = (uint32_t*)ctx->d_tile_cycles.p;
   }
   if (scene) P.scene = *scene;
+  // a deferred clear of exactly the rows this pass covers rides along; any other one runs now
+  const SvrContext::PendingClear& pc = ctx->pending_clear;
+  if (pc.valid && pc.target == ctx->color && pc.fmt == ctx->fmt && pc.y0 == ctx->sy && pc.rows == ctx->sh && ctx->sx == 0 &&
+      ctx->sw == ctx->W) {
+    P.lazy_clear = 1u;
+    P.clear_lo = (uint32_t)pc.packed;
+    P.clear_hi = (uint32_t)(pc.packed >> 32);
+    ctx->pending_clear.valid = false;
+  } else if (int e = flush_clear(ctx)) {
+    return e;
+  }
   return SVR_OK;
 }
 
@@ -816,6 +862,7 @@ int svr_bind_targets(SvrContext* ctx, void* color_dev, void* depth_dev) {
   // no fence: passes already enqueued carry their own target pointers (also for a replay), so frames
   // can alternate between target sets while earlier ones are still in flight
   if (int e = poll_pending(ctx)) return e;
+  if (int e = flush_clear(ctx)) return e;  // a deferred clear belongs to the targets it was asked for
   ctx->color = color_dev ? color_dev : ctx->color_own;
   ctx->depth = depth_dev ? (float*)depth_dev : ctx->depth_own;
   return SVR_OK;
@@ -994,19 +1041,16 @@ int svr_clear_color(SvrContext* ctx, const float rgba[4]) {
       packed |= (uint64_t)(uint32_t)std::nearbyintf(c * 255.0f) << (8 * k);
     }
   }
-  // whole rows of the scissor (a rank of the multi-GPU path only owns its band)
-  size_t px_bytes = ctx->fmt == SVR_COLOR_RGBA16F ? 8 : 4;
-  char* first_row = (char*)ctx->color + (size_t)ctx->sy * ctx->W * px_bytes;
-  int slot = 0;
-  if (int e = log_slot(ctx, &slot)) return e;
-  ctx->log.emplace_back();
-  SvrContext::LoggedOp& op = ctx->log.back();
-  op.slot = slot;
-  op.clear_rows = first_row;
-  op.clear_pixels = ctx->W * ctx->sh;
-  op.clear_fmt = ctx->fmt;
-  op.clear_packed = packed;
-  return submit_clear(ctx, op);
+  // whole rows of the scissor (a rank of the multi-GPU path only owns its band); deferred (flush_clear)
+  if (int e = flush_clear(ctx)) return e;  // an older deferred clear cannot be skipped in general
+  ctx->pending_clear.valid = true;
+  ctx->pending_clear.target = ctx->color;
+  ctx->pending_clear.y0 = ctx->sy;
+  ctx->pending_clear.rows = ctx->sh;
+  ctx->pending_clear.fmt = ctx->fmt;
+  ctx->pending_clear.packed = packed;
+  if (ctx->tuning & TUNE_NO_LAZY_CLEAR) return flush_clear(ctx);
+  return SVR_OK;
 }
 
 int svr_draw_background(SvrContext* ctx, int effect, const float data[16]) {
@@ -1015,6 +1059,7 @@ int svr_draw_background(SvrContext* ctx, int effect, const float data[16]) {
     return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_background: unknown effect");
   if (int e = use_device(ctx)) return e;
   if (int e = poll_pending(ctx)) return e;
+  if (int e = flush_clear(ctx)) return e;
   int slot = 0;
   if (int e = log_slot(ctx, &slot)) return e;
   ctx->log.emplace_back();
@@ -1043,6 +1088,7 @@ int svr_copy_to_swapchain(SvrContext* ctx, void* dst_dev, uint32_t dw, uint32_t 
   if (int e = blit_checks(ctx, dst_dev, dw, dh, fmt, "svr_copy_to_swapchain")) return e;
   if (int e = use_device(ctx)) return e;
   if (int e = poll_pending(ctx)) return e;
+  if (int e = flush_clear(ctx)) return e;
   int slot = 0;
   if (int e = log_slot(ctx, &slot)) return e;
   ctx->log.emplace_back();

@@ -25,6 +25,7 @@ constexpr uint32_t F_TRANSPARENT = 256u;
 
 // SVR_OPT_TUNING bits: switch an optimisation off at run time so it can be A/B-timed in one process
 constexpr uint32_t TUNE_NO_TILE_ORDER = 1u;   // tile kernel walks tiles row-major instead of heaviest-first
+constexpr uint32_t TUNE_NO_LAZY_CLEAR = 4u;   // svr_clear_color runs its own kernel at once instead of riding in the next pass
 constexpr uint32_t TUNE_NO_PIPELINE = 2u;     // geometry+binning on the caller's stream too (no overlap between passes)
 
 // One draw call (RenderObject after cull+sort), 128 bytes.
@@ -161,6 +162,8 @@ struct FrameParams {
   Counters* host_counters;        // pinned host copy, written by report_kernel behind the tile kernel
   uint32_t* host_failed_seq;      // pinned: op_seq of the first pass that overflowed since the last recovery (0 = none)
   uint32_t op_seq;                // this pass's number in the context's operation log (never 0)
+  uint32_t lazy_clear;            // 1: pixels this pass does not cover get the clear value clear_lo/clear_hi (deferred svr_clear_color)
+  uint32_t clear_lo, clear_hi;    // the encoded texel (RGBA16F: 4 halves; RGBA8: clear_lo)
   uint32_t flatten;               // 1: draws/chunks were built on the device; n_tris / n_chunks are upper bounds
   uint32_t* poison;               // sticky per-context flag: an earlier pass overflowed, target writes are void
   uint2* pairs;                   // [bin_cap] (bin, record): what binning scatters, in emission order
