@@ -26,7 +26,7 @@ __device__ __forceinline__ void shade_corner(const DrawDesc& d, uint32_t kind, c
     colored_triangle_mesh_vert(v, d.mat, o);
 }
 
-__global__ __launch_bounds__(256) void setup_kernel(FrameParams P) {
+__global__ __launch_bounds__(256, 4) void setup_kernel(FrameParams P) {
   uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   uint32_t lane = threadIdx.x & 63;
   // device-flattened passes: the grid was sized by the host's upper bound, the real count is on the device
@@ -168,7 +168,7 @@ __device__ int clip_polygon(VOut* poly, int n) {
 }
 
 // One lane per queued triangle, grid-stride over the device-side queue length.
-__global__ __launch_bounds__(64) void clip_kernel(FrameParams P) {
+__global__ __launch_bounds__(64, 4) void clip_kernel(FrameParams P) {
   // the setup kernel is complete (stream order): freeze the length of its part of the pair list
   if (blockIdx.x == 0 && threadIdx.x == 0) P.counters->n_pairs_setup = min(P.counters->n_pairs, P.bin_cap);
   uint32_t n = min(P.counters->n_clip, P.clip_cap);
