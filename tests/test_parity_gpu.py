@@ -198,6 +198,19 @@ def test_device_flatten_matches_the_host_path(hip, oracle):
     assert a["stats"].replayed_passes >= 1
 
 
+def test_random_cameras(hip, oracle):
+    """Seeded camera fuzz over the atrium (positions inside and outside the geometry, any pitch/yaw,
+    odd extents): the frame is the oracle's, bit for bit, every time."""
+    rng = np.random.default_rng(20261004)
+    sizes = [(256, 144), (203, 117), (320, 96)]
+    for k in range(18):
+        pos = (float(rng.uniform(-5, 65)), float(rng.uniform(0.2, 17)), float(rng.uniform(-14, 14)))
+        cam = (pos, float(rng.uniform(-1.4, 1.4)), float(rng.uniform(0, 6.283)))
+        w, h = sizes[k % 3]
+        a, b = both(T.render_sponza, hip, oracle, w, h, lod=8 if k % 2 else 4, tex_size=64, camera=cam, instrument=True)
+        assert_same(a, b, f"fuzz camera {k} {cam} {w}x{h}")
+
+
 def test_rgba8_target(hip, oracle):
     a, b = both(T.render_sponza, hip, oracle, 320, 180, lod=8, tex_size=64, color_format=A.COLOR_RGBA8, instrument=True)
     assert_same(a, b, "config3 rgba8")
