@@ -12,6 +12,8 @@
 // pairs to one list.  count_kernel takes a slot in its bin for every pair (and walks what setup could
 // not take — the clipper's records and the queued big triangles — wave per record, appending their
 // pairs with the slot already taken); offsets_kernel gives every bin a span; fill scatters.
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 
 #include "svr_bin.h"
@@ -210,9 +212,9 @@ void launch_bin_count(const FrameParams& P, hipStream_t s) {
 void launch_bin_scan(const FrameParams& P, hipStream_t s) {
   hipLaunchKernelGGL(offsets_kernel, dim3((2u * P.n_tiles + 255u) / 256u), dim3(256), 0, s, P);
 }
-void launch_bin_fill(const FrameParams& P, hipStream_t s) {
+void launch_bin_fill(const FrameParams& P, hipStream_t s, hipEvent_t done) {
   uint32_t blocks = std::max(1024u, (P.n_tiles + 255u) / 256u);
-  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, P);
+  hipExtLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, nullptr, done, 0, P);
 }
 
 }  // namespace svr

@@ -435,14 +435,11 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   if (ts >= 0 && all_stages) HIPCHK(hipEventRecord(ctx->tev[ts][1], g));
   launch_bin_count(P, g);
   launch_bin_scan(P, g);
-  launch_bin_fill(P, g);
+  launch_bin_fill(P, g, pipe ? set.ev_bin : nullptr);  // ev_bin rides on the fill kernel's dispatch
   if (ts >= 0 && all_stages) HIPCHK(hipEventRecord(ctx->tev[ts][2], g));
-  if (pipe) {
-    HIPCHK(hipEventRecord(set.ev_bin, g));
-    HIPCHK(hipStreamWaitEvent(s, set.ev_bin, 0));
-  }
+  if (pipe) HIPCHK(hipStreamWaitEvent(s, set.ev_bin, 0));
   if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][3], s));
-  launch_tiles(P, ctx->fmt, P.instrument != 0, s);
+  launch_tiles(P, ctx->fmt, P.instrument != 0, s, ctx->op_done[op_slot]);  // op_done rides on the pass's last kernel
   if (ts >= 0) {
     HIPCHK(hipEventRecord(ctx->tev[ts][4], s));
     ctx->tev_used[ts] = true;
@@ -450,7 +447,6 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   }
   HIPCHK(hipGetLastError());
   // the one event of the pass: its counters are on the host, its set and staging buffer are free
-  HIPCHK(hipEventRecord(ctx->op_done[op_slot], s));
   set.ev_tile = ctx->op_done[op_slot];
   set.used = true;
   ctx->last = P;
