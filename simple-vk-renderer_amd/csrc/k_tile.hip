@@ -85,6 +85,8 @@ struct Taps {
   uint32_t o00, o10, o01, o11;
   float alpha, beta;
 };
+// POW2: the image's extents are powers of two (part of the COMMON case): REPEAT is a mask
+template <bool POW2 = false>
 __device__ __forceinline__ Taps level_taps(const TexD& t, uint32_t level, bool linear, float u, float v) {
   int wl = (int)max(t.w >> level, 1u), hl = (int)max(t.h >> level, 1u);
   uint32_t base = mip_offset(t.lw, t.lh, level);
@@ -97,12 +99,19 @@ __device__ __forceinline__ Taps level_taps(const TexD& t, uint32_t level, bool l
   tp.beta = linear ? Vh - fv : 0.0f;
   int i0 = (int)fu, j0 = (int)fv;
   int i1 = linear ? i0 + 1 : i0, j1 = linear ? j0 + 1 : j0;
-  if (i0 < 0) i0 += wl;
-  if (i0 >= wl) i0 -= wl;
-  if (i1 >= wl) i1 -= wl;
-  if (j0 < 0) j0 += hl;
-  if (j0 >= hl) j0 -= hl;
-  if (j1 >= hl) j1 -= hl;
+  if (POW2) {  // indices are in [-1, extent]: one wrap either way == the mask
+    i0 &= wl - 1;
+    i1 &= wl - 1;
+    j0 &= hl - 1;
+    j1 &= hl - 1;
+  } else {
+    if (i0 < 0) i0 += wl;
+    if (i0 >= wl) i0 -= wl;
+    if (i1 >= wl) i1 -= wl;
+    if (j0 < 0) j0 += hl;
+    if (j0 >= hl) j0 -= hl;
+    if (j1 >= hl) j1 -= hl;
+  }
   // rows and extents are below 2^14: the 24-bit multiply is full rate where v_mul_lo_u32 is quarter rate
   const uint32_t r0 = __umul24((uint32_t)j0, (uint32_t)wl), r1 = __umul24((uint32_t)j1, (uint32_t)wl);
   tp.o00 = base + (r0 + (uint32_t)i0) * 4u;
@@ -126,7 +135,8 @@ __device__ __forceinline__ float interp3(float a0, float da1, float da2, float b
 // whole 8x8 block runs whole quads of one triangle — with ~40 triangles per tile almost no block
 // qualifies, -1 %; the 4-pixel loop is VALU-issue-bound at ~500 instructions per pixel, SQ counters
 // in DESIGN.md.)
-// COMMON: the caller knows (key bit 1) that this is mesh.frag with a LINEAR/LINEAR/MIPMAP_LINEAR sampler:
+// COMMON: the caller knows (key bit 1) that this is mesh.frag with a LINEAR/LINEAR/MIPMAP_LINEAR sampler
+// on an image with power-of-two extents:
 // pipeline kind, filter and mip-mode selections fold away (same arithmetic on the surviving path).
 template <bool TRACE, bool COMMON = false>
 __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec, int px, int py, float* trace) {
@@ -197,7 +207,7 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
   float delta = mip_linear ? lc - fl : 0.0f;
   int dlo = mip_linear ? min(dhi + 1, q) : dn;
   float us = (fabsf(u) < 8388608.0f) ? u : 0.0f, vs = (fabsf(v) < 8388608.0f) ? v : 0.0f;
-  Taps th = level_taps(t, (uint32_t)dhi, linear, us, vs);
+  Taps th = level_taps<COMMON>(t, (uint32_t)dhi, linear, us, vs);
   const uint8_t* tb = t.base;
   uint32_t h00 = *reinterpret_cast<const uint32_t*>(tb + th.o00), h10 = *reinterpret_cast<const uint32_t*>(tb + th.o10);
   uint32_t h01 = *reinterpret_cast<const uint32_t*>(tb + th.o01), h11 = *reinterpret_cast<const uint32_t*>(tb + th.o11);
@@ -208,7 +218,7 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
   Taps tl = th;
   uint32_t l00 = 0, l10 = 0, l01 = 0, l11 = 0;
   if (two_levels) {
-    tl = level_taps(t, (uint32_t)dlo, linear, us, vs);
+    tl = level_taps<COMMON>(t, (uint32_t)dlo, linear, us, vs);
     l00 = *reinterpret_cast<const uint32_t*>(tb + tl.o00);
     l10 = *reinterpret_cast<const uint32_t*>(tb + tl.o10);
     l01 = *reinterpret_cast<const uint32_t*>(tb + tl.o01);
@@ -416,7 +426,8 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
       uint32_t item = c * 64u + lane;
       uint32_t j = item >> sh, band = item & ((1u << sh) - 1u);
       bool act = item < items;
-      // owner = number of triangles whose inclusive prefix is <= j (binary search over the wave's lanes)
+      // owner = number of triangles whose inclusive prefix is <= j (binary search over the wave's lanes;
+      // a scalar compare chain for bins of <= 8 triangles was tried: no measurable difference)
       uint32_t pos = 0;
 #pragma unroll
       for (uint32_t step = 32; step >= 1; step >>= 1) {
@@ -757,7 +768,7 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
         recs[k] = ((uint32_t)v & 1u) ? resolve_record(P, main_slot, px, py) : main_slot;
       }
     }
-    __syncthreads();  // the block is reused by phase C
+    if (n_tr) __syncthreads();  // phase C reuses the block at once (phase D's own barrier covers the other case)
   }
 
   if (stamps) stamp[1] = clock64();

@@ -321,10 +321,12 @@ __device__ __forceinline__ void store_invalid(TriRec* rec) {
 // The per-triangle key the tile kernel resolves visibility and order with.  Two flag bits ride below the
 // submission number (they cannot change an order between different triangles):
 //   bit 0  the record came through the clipper: the main slot only links to the pieces
-//   bit 1  the fragment stage is the common case — mesh.frag with a LINEAR/LINEAR/MIPMAP_LINEAR sampler —
+//   bit 1  the fragment stage is the common case — mesh.frag, a LINEAR/LINEAR/MIPMAP_LINEAR sampler, an image
+//          with power-of-two extents —
 //          for which the tile kernel has a specialised instance (a wave whose pixels all carry it takes it)
 __device__ __forceinline__ uint32_t make_key(uint32_t seq, uint32_t draw_flags, const TexBinding& tex, bool clipped) {
-  bool common = ((draw_flags >> F_KIND_SHIFT) & 3u) == PIPE_MESH && (tex.info >> 24) == 7u;
+  bool pow2 = (tex.wh & 0xffffu) == (1u << (tex.info & 0xffu)) && (tex.wh >> 16) == (1u << ((tex.info >> 8) & 0xffu));
+  bool common = ((draw_flags >> F_KIND_SHIFT) & 3u) == PIPE_MESH && (tex.info >> 24) == 7u && pow2;
   return ((seq + 1u) << 2) | (common ? 2u : 0u) | (clipped ? 1u : 0u);
 }
 
