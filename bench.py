@@ -96,11 +96,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SVR_BENCH_REHEARSE=1 (development only): every rank on device 0 and gloo instead of RCCL, to walk the
+    # N > 1 code path (bands, present, in-place gather, two frame slots) on a one-GPU box; timings mean nothing
+    rehearse = os.environ.get("SVR_BENCH_REHEARSE") == "1"
+    device_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     pkg = g.load_package()
     hip = pkg.load_product_library()
@@ -108,7 +115,7 @@ def main():
     W, H = args.width, args.height
 
     sc = S.sponza_like(lod=args.lod, tex_size=args.tex_size)
-    r = hip.create(W, H, A.COLOR_RGBA16F, device=local_rank)
+    r = hip.create(W, H, A.COLOR_RGBA16F, device=device_index)
     r.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     # N > 1: the presentable B8G8R8A8 image is what the ranks exchange (4 B/px; --gather-fp16 sends the target)
     present = world > 1 and not args.gather_fp16
