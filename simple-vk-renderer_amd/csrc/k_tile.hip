@@ -7,20 +7,23 @@
 // blending (src/vk_pipelines.cpp:151-167), the depth clear to 0.0 and colour LOAD/STORE
 // (src/vk_initializers.cpp:117-164).
 //
-// One 256-thread workgroup per 32x32 tile; wave w owns the 16x16 quadrant w and lane l owns four
-// pixels of it (one per 8x8 block), so depth, sequence key and winning triangle live in VGPRs and
-// never touch LDS or HBM until the single final store.  The tile's triangle bin is staged through
-// LDS in batches of 64 (coalesced 128-byte coverage halves).  Each wave first classifies the whole
-// batch in one step (lane i tests triangle i's bbox against the wave's quadrant, __ballot), then
-// walks only the accepted triangles with the next one's LDS reads already in flight.  Coverage is
-// exact: edge functions are integers < 2^53 evaluated in fp64.
-//   phase A  opaque visibility: per pixel max over (depth, submission key) == in-order GE test
-//   phase B  shade each visible pixel once (deferred: identical result, no overdraw shading)
-//   phase C  transparent fragments peeled per pixel in submission order, blended at target precision
-//   phase D  store colour where touched, depth everywhere (the CLEAR is fused here)
-// The kernel is latency-bound, not ALU- or HBM-bound (DESIGN.md "Tile kernel"): the register budget
-// is capped for 4 workgroups per CU and every dependent-load chain is at most two deep (record ->
-// texels; the texture descriptor travels inside the record).
+// One 256-thread workgroup per 32x32 tile, launched heaviest tile first.  Pixel ownership: wave w owns
+// the 16x16 quadrant w and lane l four pixels of it (one per 8x8 block); from the end of phase A to the
+// final store their depth, key, record and colour live in VGPRs.
+//   phase A  opaque visibility by column scan: the bin is staged through LDS 64 records at a time, every
+//            triangle expands into one work item per pixel column of its bbox, a lane walks its column
+//            with exact fp64 edge increments and resolves visibility with ds_max_u64 on an LDS
+//            (depth bits << 32 | key) tile: per pixel max over (depth, submission key) == in-order
+//            GREATER_OR_EQUAL with depth write, so bins need no order
+//   phase B  shade each visible pixel once (deferred: identical result, no overdraw shading); a
+//            specialised instance serves waves whose pixels all carry the key's common-case bit
+//   phase C  transparent bin sorted by key in LDS, banded column scan (wave w owns rows 8w..8w+7) that
+//            appends depth-passing fragments to per-wave queues in submission order, shaded 64 at a
+//            time, blended at target precision; bins over 2048 entries are peeled layer by layer
+//   phase D  write-back: whole tiles go out through LDS as full rows, the depth CLEAR and a deferred
+//            svr_clear_color are fused here
+// What bounds it is VALU issue (the fragment stage is ~400-460 instructions per pixel), not HBM:
+// DESIGN.md "Tile kernel".  128 VGPRs = 4 workgroups per CU.
 #include <hip/hip_fp16.h>
 
 #include <hip/hip_ext.h>

@@ -1,12 +1,14 @@
 // svr_api.hip — the C ABI of include/svr.h over the HIP kernels (host code; no kernels here).
 //
 // Host half of VulkanEngine::draw_geometry (src/vk_engine.cpp:1357-1477): is_visible cull, sort,
-// per-draw records (the push constants + bound buffers of the record lambda, :1412-1457), then one
-// stream-ordered pass:  memset counters -> setup -> clip -> bin count -> scan -> bin fill -> tiles.
-// The pass is asynchronous like a recorded command buffer; svr_sync / readbacks are the fence.
-// Per-frame device buffers only grow.  A pass whose internal queues overflowed writes nothing to
-// the targets (every later kernel checks the flag); it is replayed with larger buffers at the next
-// fence, so results never depend on the initial capacities.
+// per-draw records (the push constants + bound buffers of the record lambda, :1412-1457) — or, for
+// large object counts, handing the objects to k_flatten.hip — then one pass of seven kernels:
+//   prologue -> setup -> clip -> count -> offsets -> fill   (internal stream: overlaps the previous tiles)
+//   tiles                                                    (caller's stream, after an event)
+// The pass is asynchronous like a recorded command buffer; svr_sync / read-backs are the fence.
+// Per-pass device buffers only grow.  A pass whose internal queues overflowed writes nothing to the
+// targets, and neither does anything after it, until the host has replayed it with larger queues
+// ("the operation log" below), so results never depend on the initial capacities.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
