@@ -245,10 +245,11 @@ int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint
 /* Implementation switches (the reference has compile-time flags only).
  * SVR_OPT_COUNT_FRAGMENTS: 1 = count rasterized/shaded fragments and binned triangles with device
  * atomics (instrumented kernels; keep 0 for timed runs).
- * SVR_OPT_KERNEL_TIMING: 1 = a hipEvent pair around the tile kernel of every pass (on the caller's
- * stream), averaged into SvrStats.tile_ms; 2 = also around geometry and binning (three more events
- * on the internal stream, a few microseconds of stream bubbles each: for profiling, not for timed
- * runs) -> SvrStats.{geometry,binning}_ms; setting the option (to 0, 1 or 2) resets the averages.
+ * SVR_OPT_KERNEL_TIMING: 1 = time the tile kernel of every pass with the start/stop events of its own
+ * dispatch (no extra packets in the stream), averaged into SvrStats.tile_ms as passes are validated;
+ * 2 = hipEvent records around geometry, binning and tiles (five more packets per pass, a few
+ * microseconds of stream bubbles each: for profiling, not for timed runs) -> SvrStats.{geometry,
+ * binning,tile}_ms; setting the option (to 0, 1 or 2) resets the averages.
  * SVR_OPT_TILE_CYCLES: 1 = every tile workgroup records the shader-clock cycles of its phases
  * (svr_debug_read_tile_cycles); five s_memtime reads per tile, off by default.
  * SVR_OPT_TUNING: bit mask that switches individual optimisations OFF (A/B timing inside one

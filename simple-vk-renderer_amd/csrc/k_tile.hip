@@ -969,23 +969,23 @@ __global__ __launch_bounds__(64) void report_kernel(FrameParams P) {
                        reinterpret_cast<const uint32_t*>(P.counters)[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// done: an event to be signalled when the pass's last kernel has finished.  It rides on that kernel's
+// start (may be null): signalled when the tile kernel starts.  done: signalled when the pass's last kernel has finished.  It rides on that kernel's
 // own dispatch packet (hipExtLaunchKernel's stopEvent): a separate hipEventRecord is one more packet
 // for the command processor between two tile kernels.
-void launch_tiles(const FrameParams& P, int color_format, bool count_fragments, hipStream_t s, hipEvent_t done) {
+void launch_tiles(const FrameParams& P, int color_format, bool count_fragments, hipStream_t s, hipEvent_t start, hipEvent_t done) {
   dim3 grid(P.n_tiles), block(256);
   const bool report = count_fragments || P.flatten;
   hipEvent_t tile_done = report ? nullptr : done;
   if (color_format == SVR_COLOR_RGBA16F) {
     if (count_fragments)
-      hipExtLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA16F, true>), grid, block, 0, s, nullptr, tile_done, 0, P);
+      hipExtLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA16F, true>), grid, block, 0, s, start, tile_done, 0, P);
     else
-      hipExtLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA16F, false>), grid, block, 0, s, nullptr, tile_done, 0, P);
+      hipExtLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA16F, false>), grid, block, 0, s, start, tile_done, 0, P);
   } else {
     if (count_fragments)
-      hipExtLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA8, true>), grid, block, 0, s, nullptr, tile_done, 0, P);
+      hipExtLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA8, true>), grid, block, 0, s, start, tile_done, 0, P);
     else
-      hipExtLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA8, false>), grid, block, 0, s, nullptr, tile_done, 0, P);
+      hipExtLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA8, false>), grid, block, 0, s, start, tile_done, 0, P);
   }
   if (report) hipExtLaunchKernelGGL(report_kernel, dim3(1), dim3(64), 0, s, nullptr, done, 0, P);
 }

@@ -139,6 +139,7 @@ struct SvrContext {
   struct LoggedOp {
     bool is_pass = false;
     uint32_t seq = 0;  // passes: running number, reported by the device if the pass overflows
+    bool timed = false;  // op_start/op_done of the slot bracket the tile kernel: fold into the running mean at retirement
     int slot = 0;  // index into h_counters / op_done
     int fill_kind = 0;  // not a pass: 0 clear, 1 background effect, 2 blit to the swapchain image
     void* clear_rows = nullptr;  // clear: first row, pixel count, format, encoded texel
@@ -160,6 +161,7 @@ struct SvrContext {
   };
   std::deque<LoggedOp> log;
   hipEvent_t op_done[MAX_OPS] = {};
+  hipEvent_t op_start[MAX_OPS] = {};  // SVR_OPT_KERNEL_TIMING level 1: start of the slot's tile kernel (rides on its dispatch)
   int op_pos = 0;
   uint32_t replayed = 0;         // passes re-run by recover_from_overflow
   // svr_clear_color deferred into the next pass (the attachment's loadOp CLEAR): see flush_clear
@@ -403,7 +405,7 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   P.chunks = (const WaveChunk*)((const char*)set.inputs.p + draw_bytes);  // DrawDesc is 128 B: stays aligned
 
   int ts = -1;
-  if (ctx->kernel_timing) {
+  if (ctx->kernel_timing >= 2) {
     ts = ctx->tev_pos;
     ctx->tev_pos = (ctx->tev_pos + 1) % SvrContext::TRING;
     if (int e = harvest_timing(ctx, ts)) return e;
@@ -441,7 +443,8 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   if (ts >= 0 && all_stages) HIPCHK(hipEventRecord(ctx->tev[ts][2], g));
   if (pipe) HIPCHK(hipStreamWaitEvent(s, set.ev_bin, 0));
   if (ts >= 0) HIPCHK(hipEventRecord(ctx->tev[ts][3], s));
-  launch_tiles(P, ctx->fmt, P.instrument != 0, s, ctx->op_done[op_slot]);  // op_done rides on the pass's last kernel
+  // op_done rides on the pass's last kernel; with kernel timing level 1 op_start rides on the tile kernel too
+  launch_tiles(P, ctx->fmt, P.instrument != 0, s, ctx->kernel_timing == 1 ? ctx->op_start[op_slot] : nullptr, ctx->op_done[op_slot]);
   if (ts >= 0) {
     HIPCHK(hipEventRecord(ctx->tev[ts][4], s));
     ctx->tev_used[ts] = true;
@@ -562,6 +565,13 @@ int retire_ops(SvrContext* ctx, bool blocking) {
       // the clears in front of the failed pass did land: only it and what follows is replayed
       ctx->log.erase(ctx->log.begin(), ctx->log.begin() + (long)k);
       return recover_from_overflow(ctx);
+    }
+    if (ctx->log[k].timed) {  // both events belong to the tile kernel's dispatch: its duration, no extra packets
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ctx->op_start[slot], ctx->op_done[slot]) == hipSuccess) {
+        ctx->acc_ms[2] += ms;
+        ctx->acc_n++;
+      }
     }
     if (ctx->log[k].P.instrument) note_pass_stats(ctx, ctx->log[k].P, ctx->h_counters[slot]);
     if (ctx->log[k].P.flatten) note_flatten_stats(ctx, ctx->h_counters[slot]);
@@ -685,6 +695,7 @@ int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& 
   op.seq = ctx->next_seq++;
   if (ctx->next_seq == 0) ctx->next_seq = 1;
   op.slot = slot;
+  op.timed = ctx->kernel_timing == 1;
   op.P = P;
   op.draws.swap(draws);
   std::memset(&ctx->h_counters[slot], 0, sizeof(Counters));
@@ -736,6 +747,7 @@ int run_pass_flatten(SvrContext* ctx, const SvrSceneData* scene, const SvrRender
   op.seq = ctx->next_seq++;
   if (ctx->next_seq == 0) ctx->next_seq = 1;
   op.slot = slot;
+  op.timed = ctx->kernel_timing == 1;
   op.P = P;
   op.objects.reserve(n_opaque + n_transparent);
   op.objects.insert(op.objects.end(), opaque, opaque + n_opaque);
@@ -801,7 +813,7 @@ int svr_create(const SvrConfig* cfg, SvrContext** out) {
   if ((r = hipHostMalloc((void**)&ctx->h_counters, sizeof(Counters) * SvrContext::MAX_OPS, hipHostMallocDefault)) != hipSuccess)
     return bail(r, "hipHostMalloc");
   for (int i = 0; i < SvrContext::MAX_OPS; i++)
-    if ((r = hipEventCreateWithFlags(&ctx->op_done[i], hipEventDisableTiming)) != hipSuccess) return bail(r, "hipEventCreate");
+    if ((r = hipEventCreate(&ctx->op_done[i])) != hipSuccess || (r = hipEventCreate(&ctx->op_start[i])) != hipSuccess) return bail(r, "hipEventCreate");
   if ((r = hipHostMalloc((void**)&ctx->h_failed_seq, 64, hipHostMallocDefault)) != hipSuccess) return bail(r, "hipHostMalloc");
   *ctx->h_failed_seq = 0;
   if ((r = hipMalloc((void**)&ctx->d_poison, 256)) != hipSuccess) return bail(r, "hipMalloc");
@@ -834,6 +846,8 @@ void svr_destroy(SvrContext* ctx) {
   if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
   for (int i = 0; i < SvrContext::MAX_OPS; i++)
     if (ctx->op_done[i]) (void)hipEventDestroy(ctx->op_done[i]);
+  for (int i = 0; i < SvrContext::MAX_OPS; i++)
+    if (ctx->op_start[i]) (void)hipEventDestroy(ctx->op_start[i]);
   if (ctx->d_poison) (void)hipFree(ctx->d_poison);
   if (ctx->h_failed_seq) (void)hipHostFree(ctx->h_failed_seq);
   for (int i = 0; i < SvrContext::TRING; i++)

@@ -19,7 +19,7 @@ void launch_bin_count(const FrameParams& P, hipStream_t s);
 void launch_bin_scan(const FrameParams& P, hipStream_t s);
 void launch_bin_fill(const FrameParams& P, hipStream_t s, hipEvent_t done);  // done: signalled with the kernel (may be null)
 // k_tile.hip
-void launch_tiles(const FrameParams& P, int color_format, bool count_fragments, hipStream_t s, hipEvent_t done);
+void launch_tiles(const FrameParams& P, int color_format, bool count_fragments, hipStream_t s, hipEvent_t start, hipEvent_t done);
 // k_image.hip
 // packed_pixel: the already encoded texel (RGBA16F: 4 halves, RGBA8: low 32 bits)
 // poison: the context's sticky overflow flag (the clear is void while it is raised)
