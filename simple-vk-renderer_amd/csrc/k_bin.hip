@@ -194,7 +194,15 @@ __global__ __launch_bounds__(256) void fill_kernel(FrameParams P) {
       uint32_t slot = l_base[cls] + rank;
       P.tile_order[slot] = t;
       P.tile_info[2u * slot] = make_uint4(t, P.tile_count[t], P.tile_offset[t], P.tile_count[P.n_tiles + t]);
-      P.tile_info[2u * slot + 1u] = make_uint4(P.tile_offset[P.n_tiles + t], 0u, 0u, 0u);
+      // a transparent bin too large for the tile kernel's LDS sort gets a span of the global sort arena
+      // (next power of two: the bitonic network pads); failing here voids the pass before it draws
+      uint32_t n_tr = P.tile_count[P.n_tiles + t], sort_base = 0;
+      if (n_tr > 2048u) {
+        uint32_t np = 1u << (32 - __clz(n_tr - 1u));
+        sort_base = atomicAdd(&P.counters->sort_used, np);
+        if (sort_base + np > P.sort_cap) atomicOr(&P.counters->overflow, 4u);
+      }
+      P.tile_info[2u * slot + 1u] = make_uint4(P.tile_offset[P.n_tiles + t], sort_base, 0u, 0u);
     }
   }
   const uint32_t n = min(P.counters->n_pairs, P.bin_cap);

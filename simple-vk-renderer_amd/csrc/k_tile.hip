@@ -19,7 +19,7 @@
 //            specialised instance serves waves whose pixels all carry the key's common-case bit
 //   phase C  transparent bin sorted by key in LDS, banded column scan (wave w owns rows 8w..8w+7) that
 //            appends depth-passing fragments to per-wave queues in submission order, shaded 64 at a
-//            time, blended at target precision; bins over 2048 entries are peeled layer by layer
+//            time, blended at target precision; bins over 2048 entries sort in a global arena instead
 //   phase D  write-back: whole tiles go out through LDS as full rows, the depth CLEAR and a deferred
 //            svr_clear_color are fused here
 // What bounds it is VALU issue (the fragment stage is ~400-460 instructions per pixel), not HBM:
@@ -33,27 +33,6 @@
 namespace svr {
 
 constexpr int BATCH = 64;  // triangles staged per LDS batch == wave size: 64 x 128 B = 8 KiB
-
-struct CovTri {  // the coverage half as read back from LDS (wave-uniform values)
-  int minx, miny;
-  uint32_t key, flags;
-  float z0, dz1, dz2, inv_area;
-  uint4 w0, w1, w2, w3, w4;  // bytes 32..111: the nine fp64 edge coefficients, decoded where used
-};
-__device__ __forceinline__ double dbl(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
-
-__device__ __forceinline__ CovTri read_cov(const uint4* s) {
-  CovTri t;
-  uint4 h = s[0];
-  t.minx = (int)(int16_t)(h.x & 0xffffu);
-  t.miny = (int)(int16_t)(h.x >> 16);
-  t.key = h.z;
-  t.flags = h.w;
-  float4 z = reinterpret_cast<const float4*>(s)[1];
-  t.z0 = z.x; t.dz1 = z.y; t.dz2 = z.z; t.inv_area = z.w;
-  t.w0 = s[2]; t.w1 = s[3]; t.w2 = s[4]; t.w3 = s[5]; t.w4 = s[6];
-  return t;
-}
 
 // ------------------------------------------------------------------------------------------------
 // texture unit (C8, C9)
@@ -313,74 +292,6 @@ struct Codec<SVR_COLOR_RGBA8> {
 };
 
 // ------------------------------------------------------------------------------------------------
-// per-pixel depth test + bookkeeping shared by both coverage paths
-template <bool PEEL>
-__device__ __forceinline__ void resolve(bool inside, float b1, float b2, const CovTri& t, uint32_t ri, uint32_t& zbit,
-                                        uint32_t& key, uint32_t& rec, uint32_t last) {
-  float z = fmaf(b2, t.dz2, fmaf(b1, t.dz1, t.z0));
-  z = fminf(fmaxf(z, 0.0f), 1.0f) + 0.0f;
-  uint32_t zb = f2u(z);
-  if (!PEEL) {
-    bool better = inside && (zb > zbit || (zb == zbit && t.key > key));
-    if (better) {
-      zbit = zb;
-      key = t.key;
-      rec = ri;
-    }
-  } else {
-    bool take = inside && zb >= zbit && t.key > last && t.key < key;
-    if (take) {
-      key = t.key;
-      rec = ri;
-    }
-  }
-}
-
-// One triangle against the blocks of the wave's quadrant selected by bm (an SGPR).
-//   PEEL == false: keep the fragment with the largest (depth, key)            (opaque visibility)
-//   PEEL == true : keep the depth-passing fragment with the smallest key > last   (next layer)
-template <bool PEEL, bool INSTR>
-__device__ __forceinline__ void raster_triangle(const CovTri& t, uint32_t ri, uint32_t bm, int ipx, int ipy,
-                                                const bool (&pix_ok)[4], uint32_t (&zbits)[4], uint32_t (&keys)[4],
-                                                uint32_t (&recs)[4], const uint32_t (&last)[4], bool count_now,
-                                                uint32_t& n_raster) {
-  int u1i = (t.flags & F_T1) ? 1 : 0, u2i = (t.flags & F_T2) ? 1 : 0;
-  double A0 = dbl(t.w0.x, t.w0.y), A1 = dbl(t.w0.z, t.w0.w), A2 = dbl(t.w1.x, t.w1.y), B0 = dbl(t.w1.z, t.w1.w);
-  double B1 = dbl(t.w2.x, t.w2.y), B2 = dbl(t.w2.z, t.w2.w), C0 = dbl(t.w3.x, t.w3.y), C1 = dbl(t.w3.z, t.w3.w);
-  double C2 = dbl(t.w4.x, t.w4.y);
-  double dpx = (double)ipx, dpy = (double)ipy;
-  double e0 = fma(A0, dpx, fma(B0, dpy, C0));
-  double e1 = fma(A1, dpx, fma(B1, dpy, C1));
-  double e2 = fma(A2, dpx, fma(B2, dpy, C2));
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    if (!(bm & (1u << k))) continue;  // bm is an SGPR (readlane): a real scalar branch, the block is skipped
-    double kx = (double)((k & 1) * 8), ky = (double)((k >> 1) * 8);
-    double f0 = fma(A0, kx, fma(B0, ky, e0));
-    double f1 = fma(A1, kx, fma(B1, ky, e1));
-    double f2 = fma(A2, kx, fma(B2, ky, e2));
-    bool inside = pix_ok[k] && f0 >= 0.0 && f1 >= 0.0 && f2 >= 0.0;
-    if (INSTR && count_now) n_raster += inside ? 1u : 0u;
-    float b1 = (float)(f1 + (double)u1i) * t.inv_area, b2 = (float)(f2 + (double)u2i) * t.inv_area;
-    resolve<PEEL>(inside, b1, b2, t, ri, zbits[k], keys[k], recs[k], last[k]);
-  }
-}
-
-// Lane i classifies triangle i of the staged batch against the wave's quadrant: bit k of the result
-// is set when the triangle's bbox touches 8x8 block k (0 = the wave can skip the triangle).
-__device__ __forceinline__ uint32_t classify(const uint4* s_cov, uint32_t lane, uint32_t cnt, int ox, int oy) {
-  if (lane >= cnt) return 0u;
-  uint4 h = s_cov[lane * 8u];
-  int minx = (int)(int16_t)(h.x & 0xffffu), miny = (int)(int16_t)(h.x >> 16);
-  int maxx = (int)(int16_t)(h.y & 0xffffu), maxy = (int)(int16_t)(h.y >> 16);
-  uint32_t cx = (maxx >= ox && minx <= ox + 7 ? 1u : 0u) | (maxx >= ox + 8 && minx <= ox + 15 ? 2u : 0u);
-  uint32_t cy = (maxy >= oy && miny <= oy + 7 ? 1u : 0u) | (maxy >= oy + 8 && miny <= oy + 15 ? 2u : 0u);
-  // block k = (k&1: column, k>>1: row)
-  return ((cx & 1u) && (cy & 1u) ? 1u : 0u) | ((cx & 2u) && (cy & 1u) ? 2u : 0u) |
-         ((cx & 1u) && (cy & 2u) ? 4u : 0u) | ((cx & 2u) && (cy & 2u) ? 8u : 0u);
-}
-
-// ------------------------------------------------------------------------------------------------
 // Phase A, column scan.  A heavy bin is mostly slivers (a distant column's quads are ~3 x 26 pixels)
 // and a whole-wave pass per triangle leaves 95 % of the lanes idle on them.  Instead every triangle of
 // a staged batch is expanded into one work item per pixel column of its tile-clamped bbox (wave prefix
@@ -493,49 +404,6 @@ __device__ __forceinline__ uint32_t resolve_record(const FrameParams& P, uint32_
   return rec;  // unreachable for a pixel that produced a fragment
 }
 
-// Walk one bin (staged through LDS) with whole-wave passes and update the per-pixel register state.
-// Used where the record of the winning fragment must be known per pixel and order matters: the
-// transparent pass (ordered walk) and its peeling fallback.
-template <bool PEEL, bool INSTR>
-__device__ __forceinline__ void walk_bin(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, uint32_t bin_base,
-                                         uint32_t n, int ox, int oy, int lx, int ly, const bool (&pix_ok)[4],
-                                         uint32_t (&zbits)[4], uint32_t (&keys)[4], uint32_t (&recs)[4],
-                                         const uint32_t (&last)[4], bool count_now, uint32_t& n_raster) {
-  const uint32_t lane = threadIdx.x & 63u;
-  for (uint32_t b0 = 0; b0 < n; b0 += BATCH) {
-    uint32_t cnt = min((uint32_t)BATCH, n - b0);
-    __syncthreads();  // previous batch fully consumed
-    for (uint32_t piece = threadIdx.x; piece < cnt * 8u; piece += 256u) {
-      uint32_t ri = P.bins[bin_base + b0 + (piece >> 3)];
-      s_cov[piece] = reinterpret_cast<const uint4*>(P.recs + ri)[piece & 7u];
-      if ((piece & 7u) == 0) s_idx[piece >> 3] = ri;
-    }
-    __syncthreads();
-    // classify the whole batch at once: lane i looks at triangle i's bbox only
-    uint32_t my_bm = classify(s_cov, lane, cnt, ox, oy);
-    unsigned long long todo = __ballot(my_bm != 0u);
-    if (!todo) continue;
-    // accepted triangles only, the next one's LDS reads in flight while this one is rasterised
-    int i = __ffsll((long long)todo) - 1;
-    todo &= todo - 1;
-    CovTri cur = read_cov(s_cov + (uint32_t)i * 8u);
-    uint32_t cri = s_idx[i];
-    for (;;) {
-      bool more = todo != 0;
-      int ni = more ? __ffsll((long long)todo) - 1 : i;
-      todo &= todo - 1;
-      CovTri nxt = read_cov(s_cov + (uint32_t)ni * 8u);
-      uint32_t nri = s_idx[ni];
-      uint32_t bm = (uint32_t)__builtin_amdgcn_readlane((int)my_bm, i);
-      raster_triangle<PEEL, INSTR>(cur, cri, bm, ox + lx, oy + ly, pix_ok, zbits, keys, recs, last, count_now, n_raster);
-      if (!more) break;
-      cur = nxt;
-      cri = nri;
-      i = ni;
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Transparent pass, ordered form.  Blending is order dependent (the target rounds after every
 // blend), so fragments must reach each pixel in submission order.  The tile's transparent bin is
@@ -548,7 +416,7 @@ __device__ __forceinline__ void walk_bin(const FrameParams& P, uint4* s_cov, uin
 // blended into the wave's LDS colour band.  Several fragments of one pixel can sit in the same group
 // of 64: they are applied in queue order by electing, per pixel, the lowest pending lane with ds_min
 // (the result of a min does not depend on lane execution order).
-constexpr uint32_t SORT_CAP = 2048;                       // bins above this fall back to per-layer peeling
+constexpr uint32_t SORT_CAP = 2048;                       // bins above this are sorted in the global sort arena instead of LDS
 constexpr uint32_t QUEUE_CAP = 128;                       // < 64 carried over + up to 64 new per row step
 constexpr uint32_t WAVE_C_BYTES = 256 * 8 + QUEUE_CAP * 8 + 256 * 4;  // colour band | queue | election slots
 constexpr uint32_t PHASE_C_BYTES = 4 * WAVE_C_BYTES + TILE * TILE * 4;  // + the tile's opaque depth bits
@@ -678,7 +546,9 @@ __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4
   while (qn) flush_fragments<FMT, INSTR>(P, col, q, slot, qn, tx0, by0, lane, n_shaded);
 }
 
-// bitonic sort of the bin's (key << 32 | record) words by all 256 threads, written back in place
+// bitonic sort of the bin's (key << 32 | record) words by all 256 threads, written back in place.
+// s: scratch for the next power of two >= n words — the LDS block for bins up to SORT_CAP, else the tile's span
+// of the global sort arena (fill_kernel reserved it; global memory is coherent inside a workgroup's CU).
 __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned long long* s, uint32_t bin_base, uint32_t n) {
   uint32_t np = 64;
   while (np < n) np <<= 1;
@@ -720,7 +590,7 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
   // tile_order).  Tiles are dealt round-robin over the 8 XCDs; a contiguous span per XCD was tried
   // and loses: the heavy rows of the frame all land on one XCD and the other seven idle.
   // One 32-byte scalar load names the tile and its two bins (fill_kernel wrote it in launch order).
-  uint32_t tile, n_op, n_tr, off_op, off_tr;
+  uint32_t tile, n_op, n_tr, off_op, off_tr, sort_base = 0;
   if (P.tuning & TUNE_NO_TILE_ORDER) {
     tile = blockIdx.x;
     n_op = P.tile_count[tile];
@@ -729,7 +599,7 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
     off_tr = P.tile_offset[P.n_tiles + tile];
   } else {
     uint4 i0 = P.tile_info[2u * blockIdx.x], i1 = P.tile_info[2u * blockIdx.x + 1u];
-    tile = i0.x; n_op = i0.y; off_op = i0.z; n_tr = i0.w; off_tr = i1.x;
+    tile = i0.x; n_op = i0.y; off_op = i0.z; n_tr = i0.w; off_tr = i1.x; sort_base = i1.y;
   }
   uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
   uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -813,10 +683,11 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
   }
   if (stamps) stamp[2] = clock64();
   // ---- phase C: transparent fragments in submission order
-  if (n_tr && n_tr <= SORT_CAP) {
+  if (n_tr) {
     uint32_t tbase = off_tr;
     int tx0 = (int)(P.sx + tx * TILE), ty0 = (int)(P.sy + ty * TILE);
-    sort_bin_by_key(P, reinterpret_cast<unsigned long long*>(s_c), tbase, n_tr);
+    if (n_tr <= SORT_CAP) sort_bin_by_key(P, reinterpret_cast<unsigned long long*>(s_c), tbase, n_tr);
+    else sort_bin_by_key(P, P.sort_arena + sort_base, tbase, n_tr);  // rare: a bin too large for LDS
     uint32_t* s_z = reinterpret_cast<uint32_t*>(s_c + 4 * WAVE_C_BYTES);
 #pragma unroll
     for (int k = 0; k < 4; k++) {  // owners publish colour and opaque depth of their pixels to the row bands
@@ -841,43 +712,6 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
       int ry = oy + (k >> 1) * 8 + ly - ty0, rx = ox + (k & 1) * 8 + lx - tx0;
       enc[k] = reinterpret_cast<const enc_t*>(s_c + (ry >> 3) * WAVE_C_BYTES)[(ry & 7) * TILE + rx];
       dirty[k] = pix_ok[k];
-    }
-  } else if (n_tr) {
-    // bins too large to sort in LDS: peel one layer per pass (cost = layers x bin, any size)
-    uint32_t last[4] = {0u, 0u, 0u, 0u};
-    bool first = true;
-    for (;;) {
-      uint32_t ck[4], cr[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        ck[k] = 0xffffffffu;
-        cr[k] = NO_REC;
-      }
-      walk_bin<true, INSTR>(P, s_cov, s_idx, off_tr, n_tr, ox, oy, lx, ly, pix_ok, zbits, ck, cr, last, first, n_raster);
-      first = false;
-      int any = (cr[0] != NO_REC) || (cr[1] != NO_REC) || (cr[2] != NO_REC) || (cr[3] != NO_REC);
-      if (!__syncthreads_or(any)) break;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (cr[k] == NO_REC) continue;
-        int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
-        size_t p = (size_t)py * P.W + (size_t)px;
-        if (!dirty[k]) enc[k] = reinterpret_cast<const enc_t*>(P.color)[p];  // colour loadOp LOAD
-        float4 dst = CD::decode(enc[k]);
-        float4 src = shade_pixel<false>(P, cr[k], px, py, nullptr);
-        if (INSTR) n_shaded++;
-        // enable_blending_additive: rgb = src*ONE + dst*DST_ALPHA, a = src*ONE + dst*ZERO
-        float4 o = make_float4(fmaf(dst.x, dst.w, src.x), fmaf(dst.y, dst.w, src.y), fmaf(dst.z, dst.w, src.z), src.w);
-        if (INSTR && P.trace_buf && px == P.trace_x && py == P.trace_y) {
-          (void)shade_pixel<true>(P, cr[k], px, py, P.trace_buf);
-          float* tb = P.trace_buf;
-          tb[32] = dst.x; tb[33] = dst.y; tb[34] = dst.z; tb[35] = dst.w;
-          tb[36] = o.x; tb[37] = o.y; tb[38] = o.z; tb[39] = o.w;
-        }
-        enc[k] = CD::encode(o);
-        dirty[k] = true;
-        last[k] = ck[k];
-      }
     }
   }
 

@@ -126,7 +126,7 @@ struct SvrContext {
   // internal stream `gstream` while the tile stage of pass N still reads set N on the caller's
   // stream.  ev_bin: set filled (recorded on gstream); ev_tile: set consumed (the pass's op_done event).
   struct PassSet {
-    DevBuf inputs, recs, clipq, bigq, tiles, bins, pairs, flat;  // flat: keys / triangle counts / chunk bases of k_flatten  // inputs = DrawDesc[] then WaveChunk[] (one H2D copy)
+    DevBuf inputs, recs, clipq, bigq, tiles, bins, pairs, flat, sorta;  // flat: keys / triangle counts / chunk bases of k_flatten  // inputs = DrawDesc[] then WaveChunk[] (one H2D copy)
     hipEvent_t ev_bin = nullptr;
     hipEvent_t ev_tile = nullptr;  // not owned: op_done of the pass that used the set last
     bool used = false;
@@ -334,6 +334,7 @@ int bind_pass_buffers(SvrContext* ctx, FrameParams& P, int set_index) {
   if (int e = set.tiles.ensure(TILE_HEAD_BYTES + ((size_t)P.n_tiles * 13 + 8) * sizeof(uint32_t))) return e;
   if (int e = set.bins.ensure((size_t)ctx->bin_cap * sizeof(uint32_t))) return e;
   if (int e = set.pairs.ensure((size_t)ctx->bin_cap * 12)) return e;
+  if (int e = set.sorta.ensure((size_t)ctx->bin_cap * 2 * sizeof(unsigned long long))) return e;
   P.recs = (TriRec*)set.recs.p;
   P.extra_cap = ctx->extra_cap;
   P.clip_queue = (ClipItem*)set.clipq.p;
@@ -349,6 +350,8 @@ int bind_pass_buffers(SvrContext* ctx, FrameParams& P, int set_index) {
   P.pair_slot = (uint32_t*)((char*)set.pairs.p + (size_t)ctx->bin_cap * 8);
   P.bins = (uint32_t*)set.bins.p;
   P.bin_cap = ctx->bin_cap;
+  P.sort_arena = (unsigned long long*)set.sorta.p;
+  P.sort_cap = ctx->bin_cap * 2u;  // a sorted bin needs at most twice its entries (power-of-two padding)
   P.poison = ctx->d_poison;
   P.host_failed_seq = ctx->h_failed_seq;
   return SVR_OK;
@@ -835,7 +838,7 @@ void svr_destroy(SvrContext* ctx) {
     if (im.base) (void)hipFree(im.base);
   DevBuf* bufs[] = {&ctx->tex_table, &ctx->d_cvt, &ctx->d_trace, &ctx->d_tile_cycles, &ctx->mesh_table, &ctx->mat_table};
   for (auto& set : ctx->sets) {
-    DevBuf* sb[] = {&set.inputs, &set.recs, &set.clipq, &set.bigq, &set.tiles, &set.bins, &set.pairs, &set.flat};
+    DevBuf* sb[] = {&set.inputs, &set.recs, &set.clipq, &set.bigq, &set.tiles, &set.bins, &set.pairs, &set.flat, &set.sorta};
     for (DevBuf* b : sb) b->release();
     if (set.ev_bin) (void)hipEventDestroy(set.ev_bin);
   }

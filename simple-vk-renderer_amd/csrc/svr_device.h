@@ -116,7 +116,7 @@ struct Counters {
   uint32_t n_big;          // triangles over 16 tiles queued by the setup kernel (binned wave-per-record)
   uint32_t n_pairs;        // (bin, record) pairs appended so far (keeps counting past pair capacity)
   uint32_t n_pairs_setup;  // n_pairs when the setup kernel had finished (snapshot taken by clip_kernel)
-  uint32_t pad32;
+  uint32_t sort_used;      // words of the sort arena handed out to transparent bins too large for an LDS sort
   unsigned long long pad[1];
   // device flatten (k_flatten.hip): what the host only knows upper bounds of
   uint32_t flat_draws;     // draws after culling (visible opaque + transparent)
@@ -168,7 +168,9 @@ struct FrameParams {
   uint32_t* poison;               // sticky per-context flag: an earlier pass overflowed, target writes are void
   uint2* pairs;                   // [bin_cap] (bin, record): what binning scatters, in emission order
   uint32_t* pair_slot;            // [bin_cap] position of the pair inside its bin
-  uint4* tile_info;               // [2*n_tiles] launch slot -> {tile, n_opaque, offset_opaque, n_transparent}, {offset_transparent,-,-,-}
+  uint4* tile_info;               // [2*n_tiles] launch slot -> {tile, n_opaque, offset_opaque, n_transparent}, {offset_transparent, sort_base,-,-}
+  unsigned long long* sort_arena; // [sort_cap] (key << 32 | record) scratch of transparent bins over the LDS sort capacity
+  uint32_t sort_cap;
   uint32_t* tile_order;           // [n_tiles] launch order of the tile kernel, heaviest first
   uint32_t* bins;
   uint32_t bin_cap;

@@ -254,7 +254,7 @@ def random_soup(lib, w=160, h=96, n_tris=600, seed=7, transparent_every=5, color
 def transparent_stack(lib, n_layers, size=48, jitter=0.0, seed=21):
     """n_layers small transparent quads stacked on the same pixels (one 32x32 tile holds 2*n_layers
     triangles): deep in-order blending.  More than 1024 layers exceeds the tile kernel's LDS sort
-    capacity and takes its per-layer fallback."""
+    capacity (2048 entries) and sorts in the global arena."""
     rng = np.random.default_rng(seed)
     rig = Rig(lib, size, size, background=(0.0, 0.0, 0.0, 1))
     verts, idx = [], []
