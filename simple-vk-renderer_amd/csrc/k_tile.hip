@@ -652,6 +652,10 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
   for (int k = 0; k < 4; k++) {
     dirty[k] = recs[k] != NO_REC;
     enc[k] = enc_t();
+  }
+  uint32_t generic_slots = 0;  // wave-uniform: pixel slots in which some lane needs the generic fragment stage
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
     int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
     if (__all(!dirty[k] || (keys[k] & 2u))) {  // every shaded pixel of the wave is the common case
       if (dirty[k]) {
@@ -661,11 +665,30 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
           if (P.trace_buf && px == P.trace_x && py == P.trace_y) (void)shade_pixel<true>(P, recs[k], px, py, P.trace_buf);
         }
       }
-    } else if (dirty[k]) {
-      enc[k] = CD::encode(shade_pixel<false>(P, recs[k], px, py, nullptr));
-      if (INSTR) {
-        n_shaded++;
-        if (P.trace_buf && px == P.trace_x && py == P.trace_y) (void)shade_pixel<true>(P, recs[k], px, py, P.trace_buf);
+    } else {
+      generic_slots |= 1u << k;
+    }
+  }
+  if (generic_slots) {
+    // Anything but the common case goes through ONE rolled instance of the generic stage (k is a run-time
+    // value, the per-slot state is picked with selects): four unrolled copies of it in this kernel cost
+    // the common path registers and instruction-cache room for nothing.
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+      if (!((generic_slots >> k) & 1u)) continue;
+      uint32_t rec = k == 0 ? recs[0] : (k == 1 ? recs[1] : (k == 2 ? recs[2] : recs[3]));
+      bool d = k == 0 ? dirty[0] : (k == 1 ? dirty[1] : (k == 2 ? dirty[2] : dirty[3]));
+      int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
+      if (d) {
+        enc_t e = CD::encode(shade_pixel<false>(P, rec, px, py, nullptr));
+        enc[0] = k == 0 ? e : enc[0];
+        enc[1] = k == 1 ? e : enc[1];
+        enc[2] = k == 2 ? e : enc[2];
+        enc[3] = k == 3 ? e : enc[3];
+        if (INSTR) {
+          n_shaded++;
+          if (P.trace_buf && px == P.trace_x && py == P.trace_y) (void)shade_pixel<true>(P, rec, px, py, P.trace_buf);
+        }
       }
     }
   }
