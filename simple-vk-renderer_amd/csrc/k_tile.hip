@@ -586,7 +586,7 @@ template <int FMT, bool INSTR>
 __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, unsigned char* s_c) {
   typedef Codec<FMT> CD;
   typedef typename CD::enc_t enc_t;
-  // Workgroups are dispatched in blockIdx order: walk the tiles heaviest class first (scan_kernel's
+  // Workgroups are dispatched in blockIdx order: walk the tiles heaviest class first (fill_kernel's
   // tile_order).  Tiles are dealt round-robin over the 8 XCDs; a contiguous span per XCD was tried
   // and loses: the heavy rows of the frame all land on one XCD and the other seven idle.
   // One 32-byte scalar load names the tile and its two bins (fill_kernel wrote it in launch order).

@@ -179,7 +179,7 @@ struct SvrContext {
   DevBuf d_cvt;
   uint32_t clip_cap = 0, extra_cap = 0, bin_cap = 0;
   uint32_t debug_caps = 0;  // SVR_OPT_QUEUE_CAPS
-  // pinned host staging (ring) + readback
+  // pinned host staging + read-back, one of each per operation-log slot
   void* h_stage[MAX_OPS] = {};  // per log slot
   size_t h_stage_cap[MAX_OPS] = {};
   Counters* h_counters = nullptr;  // pinned, [MAX_OPS]
@@ -357,7 +357,7 @@ int bind_pass_buffers(SvrContext* ctx, FrameParams& P, int set_index) {
   return SVR_OK;
 }
 
-// Enqueue one pass.  Stage 1 (gstream): inputs H2D, memset, setup, clip, bin count, scan, bin fill
+// Enqueue one pass.  Stage 1 (gstream): prologue (inputs + zeroing), setup, clip, bin count, offsets, bin fill
 // -> ev_bin.  Stage 2 (caller's stream): wait ev_bin, tile kernel, counters to the host
 // (report_kernel) -> op_done.  The caller sees stream order (everything it enqueued before the call precedes the tile
 // stage, the only one that touches the targets); stage 1 depends on host inputs alone, so it overlaps
