@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--lod", type=int, default=1, help="tessellation divisor of the scene generator (1 = 262,144 triangles)")
     ap.add_argument("--tex-size", type=int, default=1024)
     ap.add_argument("--instances", type=int, default=1, help="16 = BASELINE config 5's 4x4 instancing")
+    ap.add_argument("--gltf", default="", help="render this .glb/.gltf instead of the synthetic scene (not the BASELINE workload)")
+    ap.add_argument("--camera", default="", help="with --gltf: x,y,z,pitch,yaw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-fp16", action="store_true", help="N > 1: all-gather the RGBA16F target instead of the swapchain image")
     ap.add_argument("--cpu-frames", type=int, default=3)
@@ -66,7 +68,7 @@ def cpu_baseline(args, pkg, shaded_per_frame, sc):
     handles = sc.upload(r)
     inst = S.config5_instances() if args.instances == 16 else None
     opaque, transparent = sc.render_objects(handles, instance_transforms=inst)
-    pos, pitch, yaw = S.config5_camera() if args.instances == 16 else S.config3_camera()
+    pos, pitch, yaw = camera_of(args, S)
     scene = S.scene_data_struct(pos, pitch, yaw, args.width, args.height)
     ora.lib.svr_oracle_set_threads(r.h, cores)
     r.clear_color((1, 1, 1, 1))
@@ -82,6 +84,20 @@ def cpu_baseline(args, pkg, shaded_per_frame, sc):
             "sample": f"{args.cpu_frames} full frames of the same workload ({args.width}x{args.height}) after 1 warm-up, "
                       f"geometry single-threaded, rasterisation row-band parallel over {cores} threads; "
                       "fragments counted as the GPU path counts them (each visible pixel once + transparent layers)"}
+
+
+def load_scene(args, pkg):
+    if args.gltf:
+        import importlib
+        return importlib.import_module(pkg.__name__ + ".gltf_io").load_gltf(args.gltf)
+    return pkg.scenes.sponza_like(lod=args.lod, tex_size=args.tex_size)
+
+
+def camera_of(args, S):
+    if args.gltf and args.camera:
+        v = [float(x) for x in args.camera.split(",")]
+        return (v[0], v[1], v[2]), v[3], v[4]
+    return S.config5_camera() if args.instances == 16 else S.config3_camera()
 
 
 def main():
@@ -114,7 +130,7 @@ def main():
     S, A, D = pkg.scenes, pkg.abi, pkg.dist
     W, H = args.width, args.height
 
-    sc = S.sponza_like(lod=args.lod, tex_size=args.tex_size)
+    sc = load_scene(args, pkg)
     r = hip.create(W, H, A.COLOR_RGBA16F, device=device_index)
     r.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     # N > 1: the presentable B8G8R8A8 image is what the ranks exchange (4 B/px; --gather-fp16 sends the target)
@@ -123,7 +139,7 @@ def main():
     handles = sc.upload(r)
     inst = S.config5_instances() if args.instances == 16 else None
     opaque, transparent = sc.render_objects(handles, instance_transforms=inst)
-    pos, pitch, yaw = S.config5_camera() if args.instances == 16 else S.config3_camera()
+    pos, pitch, yaw = camera_of(args, S)
     scene = S.scene_data_struct(pos, pitch, yaw, W, H)
     state = {"i": 0}
 
@@ -195,11 +211,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"sponza-style synthetic scene seed 0x53505A41, {counts_scene['triangles']} triangles"
-                                   f" x{args.instances} instances, {W}x{H}, RGBA16F+D32, mesh.vert/mesh.frag"
-                                   f" (BASELINE configs[{4 if args.instances == 16 else 3}])",
+            "config": {"workload": (f"glTF file {os.path.basename(args.gltf)}, {counts_scene['triangles']} triangles, {W}x{H}, RGBA16F+D32,"
+                                    " mesh.vert/mesh.frag (NOT a BASELINE config)") if args.gltf else
+                                   (f"sponza-style synthetic scene seed 0x53505A41, {counts_scene['triangles']} triangles"
+                                    f" x{args.instances} instances, {W}x{H}, RGBA16F+D32, mesh.vert/mesh.frag"
+                                    f" (BASELINE configs[{4 if args.instances == 16 else 3}])"),
                        "width": W, "height": H, "triangles": counts_scene["triangles"] * args.instances,
-                       "draws": int(len(opaque) + len(transparent)), "textures": f"25 x {args.tex_size}^2 RGBA8 mipmapped",
+                       "draws": int(len(opaque) + len(transparent)),
+                       "textures": f"{len(sc.textures)} images from the file" if args.gltf else f"25 x {args.tex_size}^2 RGBA8 mipmapped",
                        "parallelism": (f"row bands x{world} + all_gather of the " + ("B8G8R8A8 swapchain image" if present else "RGBA16F target"))
                                       if world > 1 else "single GPU"},
             "frames_per_s": fps,

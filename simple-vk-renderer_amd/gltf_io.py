@@ -124,3 +124,157 @@ def write_glb(scene, path, node_locals=None):
         f.write(struct.pack("<II", len(js), 0x4E4F534A) + js)
         f.write(struct.pack("<II", len(binc), 0x004E4942) + binc)
     return total
+
+
+# ------------------------------------------------------------------------------------------------
+# Reading: the Python counterpart of host/svr_gltf.cpp (same rules, same quirks), so that the Python
+# drivers (bench.py --gltf, tools/frames.py --gltf, tests) can render an asset file the way the C++
+# host does.  Images are decoded with Pillow here (driver-side convenience); the product's own loader
+# is the C++ one.
+_COMP = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
+_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4}
+
+
+def _read_container(path):
+    import base64
+    import os
+    with open(path, "rb") as f:
+        raw = f.read()
+    base = os.path.dirname(os.path.abspath(path))
+    glb_bin = None
+    if raw[:4] == b"glTF":
+        total = struct.unpack_from("<I", raw, 8)[0]
+        pos, doc = 12, None
+        while pos + 8 <= min(total, len(raw)):
+            n, kind = struct.unpack_from("<II", raw, pos)
+            body = raw[pos + 8:pos + 8 + n]
+            if kind == 0x4E4F534A:
+                doc = json.loads(body.decode("utf-8"))
+            elif kind == 0x004E4942 and glb_bin is None:
+                glb_bin = body
+            pos += 8 + ((n + 3) & ~3)
+    else:
+        doc = json.loads(raw.decode("utf-8"))
+
+    def uri_bytes(uri):
+        if uri.startswith("data:"):
+            return base64.b64decode(uri.split(",", 1)[1])
+        from urllib.parse import unquote
+        with open(os.path.join(base, unquote(uri)), "rb") as f:
+            return f.read()
+
+    buffers = []
+    for i, b in enumerate(doc.get("buffers", [])):
+        buffers.append(uri_bytes(b["uri"]) if "uri" in b else (glb_bin if i == 0 else b""))
+    return doc, buffers, uri_bytes
+
+
+def _accessor(doc, buffers, index):
+    """-> float32 [count, ncomp] (integers converted as the C++ loader / fastgltf do) and the raw ints."""
+    acc = doc["accessors"][index]
+    bv = doc["bufferViews"][acc["bufferView"]]
+    dt = np.dtype(_COMP[acc["componentType"]])
+    nc = _NCOMP[acc["type"]]
+    start = bv.get("byteOffset", 0) + acc.get("byteOffset", 0)
+    stride = bv.get("byteStride", 0) or dt.itemsize * nc
+    buf = np.frombuffer(buffers[bv["buffer"]], dtype=np.uint8)
+    count = acc["count"]
+    rows = np.lib.stride_tricks.as_strided(buf[start:], shape=(count, dt.itemsize * nc), strides=(stride, 1))
+    vals = np.ascontiguousarray(rows).view(dt).reshape(count, nc)
+    if dt == np.float32:
+        return vals, vals
+    f = vals.astype(np.float32)
+    if acc.get("normalized"):
+        scale = {np.dtype(np.uint8): 255.0, np.dtype(np.uint16): 65535.0, np.dtype(np.int8): 127.0, np.dtype(np.int16): 32767.0}[dt]
+        f = f / np.float32(scale)
+        if dt.kind == "i":
+            f = np.maximum(f, np.float32(-1.0))
+    return f.astype(np.float32), vals
+
+
+def load_gltf(path):
+    """.glb / .gltf -> scenes.Scene, packed as load_gltf_meshes packs it (src/vk_loader.cpp:162-437).
+    The engine's defaults a file can fall back on are appended to the scene's own lists: the last texture
+    is the 1x1 white image, the one before it the error checkerboard; the last sampler is the default
+    linear one (src/vk_engine.cpp:231-261)."""
+    from . import glmath, scenes
+    doc, buffers, uri_bytes = _read_container(path)
+    sc = scenes.Scene()
+    TRI = dict(min_lod=0.0, max_lod=1000.0)
+    nearest, linear = (9728, 9984, 9986), None
+    for s in doc.get("samplers", []):
+        mag, minf = s.get("magFilter", 9728), s.get("minFilter", 9728)
+        sc.samplers.append(dict(mag=abi.FILTER_NEAREST if mag in nearest else abi.FILTER_LINEAR,
+                                minf=abi.FILTER_NEAREST if minf in nearest else abi.FILTER_LINEAR,
+                                mip=abi.MIPMAP_NEAREST if minf in (9984, 9985) else abi.MIPMAP_LINEAR, **TRI))
+    failed = []
+    for i, im in enumerate(doc.get("images", [])):
+        try:
+            import io
+            from PIL import Image
+            if "uri" in im:
+                data = uri_bytes(im["uri"])
+            else:
+                bv = doc["bufferViews"][im["bufferView"]]
+                data = buffers[bv["buffer"]][bv.get("byteOffset", 0):bv.get("byteOffset", 0) + bv["byteLength"]]
+            img = Image.open(io.BytesIO(data))
+            if img.mode in ("I;16", "I;16B", "I"):
+                raise ValueError("16-bit greyscale is left to the C++ loader")
+            sc.textures.append(np.ascontiguousarray(np.asarray(img.convert("RGBA"), dtype=np.uint8)))
+            sc.texture_mips.append(True)
+        except Exception:  # the reference substitutes the error checkerboard (src/vk_loader.cpp:226-231)
+            failed.append(i)
+            sc.textures.append(None)
+            sc.texture_mips.append(False)
+    checker_index, white_index = len(sc.textures), len(sc.textures) + 1
+    sc.textures += [scenes.checkerboard_32(), scenes.white_1x1()]
+    sc.texture_mips += [False, False]
+    for i in failed:
+        sc.textures[i], sc.texture_mips[i] = sc.textures[checker_index], False
+    default_linear = len(sc.samplers)
+    sc.samplers.append(dict(scenes.SAMPLER_LINEAR))
+    for m in doc.get("materials", []):
+        pbr = m.get("pbrMetallicRoughness", {})
+        tex, smp = white_index, default_linear
+        if "baseColorTexture" in pbr:
+            t = doc["textures"][pbr["baseColorTexture"]["index"]]
+            tex, smp = t["source"], t["sampler"]
+        sc.materials.append(dict(pass_type=abi.PASS_TRANSPARENT if m.get("alphaMode") == "BLEND" else abi.PASS_MAIN_COLOR,
+                                 color_factors=tuple(float(x) for x in pbr.get("baseColorFactor", (1, 1, 1, 1))),
+                                 texture=tex, sampler=smp,
+                                 metal_rough=(float(pbr.get("metallicFactor", 1.0)), float(pbr.get("roughnessFactor", 1.0)))))
+    for mesh in doc.get("meshes", []):
+        asset = scenes.MeshAsset(mesh.get("name", ""))
+        for p in mesh["primitives"]:
+            attrs = p["attributes"]
+            pos, _ = _accessor(doc, buffers, attrs["POSITION"])
+            n = pos.shape[0]
+            get = lambda name: _accessor(doc, buffers, attrs[name])[0] if name in attrs else None
+            nrm, uv, col = get("NORMAL"), get("TEXCOORD_0"), get("COLOR_0")
+            if col is not None and col.shape[1] == 3:
+                col = np.concatenate([col, np.ones((col.shape[0], 1), np.float32)], axis=1)
+            idx = _accessor(doc, buffers, p["indices"])[1].reshape(-1).astype(np.uint32) if "indices" in p else np.arange(n, dtype=np.uint32)
+            asset.add_primitive(pos[:, :3], nrm[:, :3] if nrm is not None else None, uv[:, :2] if uv is not None else None,
+                                idx, int(p.get("material", 0)), colors=col)
+        sc.meshes.append(asset)
+    nodes = doc.get("nodes", [])
+
+    def local(n):
+        if "matrix" in n:
+            return np.array(n["matrix"], dtype=np.float32).reshape(4, 4)
+        return glmath.trs(n.get("translation", (0, 0, 0)), n.get("rotation", (0, 0, 0, 1)), n.get("scale", (1, 1, 1)))
+
+    children = {c for n in nodes for c in n.get("children", [])}
+    ident = glmath.identity()
+
+    def visit(i):  # LoadedGLTF::Draw: top nodes in file order, each depth first; world = identity * local (quirk D8)
+        n = nodes[i]
+        if "mesh" in n:
+            sc.nodes.append((int(n["mesh"]), glmath.matmul(ident, local(n))))
+        for c in n.get("children", []):
+            visit(c)
+
+    for i in range(len(nodes)):
+        if i not in children:
+            visit(i)
+    return sc

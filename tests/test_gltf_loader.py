@@ -408,3 +408,47 @@ def test_gltf_loader_rejects_broken_files(tmp_path, oracle):
 def test_gltf_loader_on_the_hip_library(tmp_path, hip, oracle):
     check_atrium(hip, tmp_path, oracle)
     check_handwritten(hip, tmp_path, oracle)
+
+
+def test_python_loader_round_trip(tmp_path, oracle):
+    """gltf_io.load_gltf (the Python drivers' loader) reads back what write_glb wrote: same geometry and
+    textures, and the identical frame."""
+    sc = S.sponza_like(lod=8, tex_size=64)
+    glb = str(tmp_path / "rt.glb")
+    IO.write_glb(sc, glb)
+    back = IO.load_gltf(glb)
+    assert back.counts() == sc.counts()
+    for a, b in zip(sc.meshes, back.meshes):
+        assert a.vertices.tobytes() == b.vertices.tobytes() and a.indices.tobytes() == b.indices.tobytes()
+    for a, b in zip(sc.textures, back.textures):
+        assert np.array_equal(a, b)
+    cam = S.config3_camera()
+    frames = []
+    for scene_obj in (sc, back):
+        r = oracle.create(W, H)
+        handles = scene_obj.upload(r)
+        op, tr = scene_obj.render_objects(handles)
+        r.clear_color((1, 1, 1, 1))
+        r.draw_geometry(S.scene_data_struct(*cam, W, H), op, tr)
+        frames.append(T._finish(r))
+        r.close()
+    T.assert_images_identical(frames[0]["color"], frames[1]["color"], "round-trip colour")
+    T.assert_images_identical(frames[0]["depth"], frames[1]["depth"], "round-trip depth")
+
+
+def test_python_loader_agrees_with_the_cpp_loader(tmp_path, oracle):
+    """The hand-written file through both loaders: the C++ host's frame and the Python loader's."""
+    path, _sc, _doc, _d = build_handwritten(tmp_path)
+    demo = run_demo(oracle.path, path, str(tmp_path / "h2"), (0.0, 0.0, 0.0, 0.0, 0.0))
+    sc = IO.load_gltf(path)
+    assert sc.counts()["surfaces"] == 9 and len(sc.materials) == 8
+    r = oracle.create(W, H)
+    engine_defaults(r)
+    handles = sc.upload(r)
+    op, tr = sc.render_objects(handles)
+    r.draw_background(A.BACKGROUND_GRADIENT, A.GRADIENT_DEFAULT)
+    r.draw_geometry(A.SvrSceneData.from_buffer_copy(demo["scene"].tobytes()), op, tr)
+    out = T._finish(r)
+    r.close()
+    T.assert_images_identical(demo["color"], out["color"], "C++ loader vs Python loader colour")
+    T.assert_images_identical(demo["depth"], out["depth"], "C++ loader vs Python loader depth")
