@@ -201,7 +201,7 @@ def main():
         # process; the committed rocprofv3 --pmc summary of this very command (1 GPU, default size) is quoted
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "r01_f_traffic.json")
-        if world == 1 and (W, H, args.instances, args.lod) == (3840, 2160, 1, 1) and os.path.exists(tpath):
+        if world == 1 and not args.gltf and (W, H, args.instances, args.lod, args.tex_size) == (3840, 2160, 1, 1, 1024) and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             traffic, traffic_source = tj["traffic_bytes_per_launch"], "profiles/r01_f_traffic.json: " + tj["correction"]
