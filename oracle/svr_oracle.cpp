@@ -8,7 +8,9 @@
 // cannot be built here (needs Vulkan, GLFW, glm, fastgltf, VMA, ImGui; submodule dirs are empty).
 // The oracle is therefore a restatement of the reference's shaders and pipeline state plus the
 // Vulkan rules for the fixed-function stages, pinned only by analytic known-answer tests
-// (tests/test_oracle_kat.py).  Where Vulkan leaves arithmetic implementation-defined, DESIGN.md
+// (tests/test_oracle_kat.py).  (The one runnable piece of the reference, its vendored stb_image, pins the
+// glTF loader's image decoders instead: oracle/ref_stb_decode.cpp, tests/make_golden_images.py.)
+// Where Vulkan leaves arithmetic implementation-defined, DESIGN.md
 // §"Arithmetic contract" (C0..C13) fixes one choice; the comments below cite those items.
 //
 // What is restated, with the reference file:line each part follows:

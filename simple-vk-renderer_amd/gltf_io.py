@@ -62,9 +62,11 @@ class _Bin:
         return len(self.accessors) - 1
 
 
-def write_glb(scene, path, node_locals=None):
+def write_glb(scene, path, node_locals=None, image_format="PNG"):
     """scene: scenes.Scene.  Nodes are written flat, each with its world matrix as `matrix`, unless
-    node_locals gives [(mesh or None, 4x4 local, [children])] to write a hierarchy verbatim."""
+    node_locals gives [(mesh or None, 4x4 local, [children])] to write a hierarchy verbatim.
+    image_format "JPEG" stores the textures lossily (Pillow, RGB, quality 90, 4:2:0): for exercising the
+    loader's JPEG path, not for bit comparisons with the directly uploaded scene."""
     b = _Bin()
     meshes = []
     for mesh in scene.meshes:
@@ -79,8 +81,17 @@ def write_glb(scene, path, node_locals=None):
             prims.append({"attributes": attrs, "indices": b.accessor(idx.astype(np.uint32), 5125, "SCALAR", 34963),
                           "material": int(s.material), "mode": 4})
         meshes.append({"name": mesh.name, "primitives": prims})
-    images = [{"name": f"image{i}", "mimeType": "image/png", "bufferView": b.view(png_encode(t))}
-              for i, t in enumerate(scene.textures)]
+    def encode(t):
+        if image_format == "PNG":
+            return png_encode(t)
+        import io
+        from PIL import Image
+        buf = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(t[..., :3])).save(buf, "JPEG", quality=90)
+        return buf.getvalue()
+
+    mime = "image/png" if image_format == "PNG" else "image/jpeg"
+    images = [{"name": f"image{i}", "mimeType": mime, "bufferView": b.view(encode(t))} for i, t in enumerate(scene.textures)]
     samplers = []
     for s in scene.samplers:
         mip = s["mip"] if s.get("max_lod", 0.0) > 0.0 else None

@@ -13,6 +13,7 @@
 #include <string>
 
 #include "svr_engine.h"
+#include "svr_jpeg.h"
 #include "svr_png.h"
 
 using namespace svrhost;
@@ -69,14 +70,26 @@ int main(int argc, char** argv) {
   if (!png.empty()) {  // decoder check: PNG file -> <prefix>.rgba (tests/test_gltf_loader.py)
     std::ifstream f(png, std::ios::binary);
     std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-    svrpng::Image img;
     std::string err;
-    if (!svrpng::decode(bytes.data(), bytes.size(), img, &err)) {
-      fprintf(stderr, "png: %s\n", err.c_str());
-      return 1;
+    uint32_t iw = 0, ih = 0;
+    std::vector<uint8_t> rgba;
+    if (bytes.size() >= 2 && bytes[0] == 0xff && bytes[1] == 0xd8) {
+      svrjpeg::Image img;
+      if (!svrjpeg::decode(bytes.data(), bytes.size(), img, &err)) {
+        fprintf(stderr, "png: %s\n", err.c_str());
+        return 1;
+      }
+      iw = img.w; ih = img.h; rgba.swap(img.rgba);
+    } else {
+      svrpng::Image img;
+      if (!svrpng::decode(bytes.data(), bytes.size(), img, &err)) {
+        fprintf(stderr, "png: %s\n", err.c_str());
+        return 1;
+      }
+      iw = img.w; ih = img.h; rgba.swap(img.rgba);
     }
-    printf("png %u %u\n", img.w, img.h);
-    if (!prefix.empty()) dump(prefix + ".rgba", img.rgba.data(), img.rgba.size());
+    printf("png %u %u\n", iw, ih);
+    if (!prefix.empty()) dump(prefix + ".rgba", rgba.data(), rgba.size());
     return 0;
   }
   if (lib.empty()) {

@@ -4,9 +4,10 @@
 //
 // Covered: colour types 0/2/3/4/6, bit depths 1-16 (16-bit samples keep their high byte, as stb does),
 // PLTE + tRNS (palette alpha, and the grey / RGB colour key), Adam7 interlace.  Chunk CRCs and the
-// zlib Adler-32 are not verified (stb_image does not verify them either).  JPEG and the other formats
-// stb_image reads are not covered: load fails and the loader falls back to the error checkerboard,
-// which is what the reference does for an image it cannot decode (src/vk_loader.cpp:226-231).
+// zlib Adler-32 are not verified (stb_image does not verify them either).  Pinned byte for byte against
+// the reference's decoder by tests/golden/images.npz (tests/test_image_decoders.py).  JPEG: svr_jpeg.h;
+// the other formats stb_image reads are not covered: load fails and the loader falls back to the error
+// checkerboard, which is what the reference does for an image it cannot decode (src/vk_loader.cpp:226-231).
 #pragma once
 #include <cstdint>
 #include <cstring>

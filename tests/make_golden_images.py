@@ -63,6 +63,11 @@ def pillow_cases(rng):
     cases.append(("jpg_opt", save(Image.fromarray(noise(40, 40, 3), "RGB"), "JPEG", quality=50, optimize=True)))
     cases.append(("jpg_q100", save(Image.fromarray(noise(24, 24, 3), "RGB"), "JPEG", quality=100, subsampling=0)))
     cases.append(("jpg_q5", save(Image.fromarray(noise(32, 24, 3), "RGB"), "JPEG", quality=5)))
+    big = Image.fromarray(noise(70, 50, 3), "RGB")
+    cases.append(("jpg_rst_blocks", save(big, "JPEG", quality=80, subsampling=2, restart_marker_blocks=3)))
+    cases.append(("jpg_rst_rows", save(big, "JPEG", quality=80, subsampling=0, restart_marker_rows=1)))
+    cases.append(("jpg_rst_prog", save(big, "JPEG", quality=70, subsampling=1, progressive=True, restart_marker_blocks=5)))
+    cases.append(("jpg_411", save(big, "JPEG", quality=85, subsampling="4:1:1") if hasattr(Image, "core") else b""))
     return cases
 
 
