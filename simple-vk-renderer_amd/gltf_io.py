@@ -139,9 +139,8 @@ def write_glb(scene, path, node_locals=None, image_format="PNG"):
 
 # ------------------------------------------------------------------------------------------------
 # Reading: the Python counterpart of host/svr_gltf.cpp (same rules, same quirks), so that the Python
-# drivers (bench.py --gltf, tools/frames.py --gltf, tests) can render an asset file the way the C++
-# host does.  Images are decoded with Pillow here (driver-side convenience); the product's own loader
-# is the C++ one.
+# drivers (bench.py --gltf, tests) can render an asset file the way the C++ host does.  Images go through
+# the host's own decoders when the harness is built (Pillow otherwise: driver-side convenience).
 _COMP = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
 _NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4}
 
@@ -203,6 +202,26 @@ def _accessor(doc, buffers, index):
     return f.astype(np.float32), vals
 
 
+def _host_decode(data):
+    """PNG / JPEG bytes -> RGBA8 through host/svr_demo --png (svr_png.h / svr_jpeg.h), or None if the host
+    harness is not built or refuses the file (the caller then falls back to Pillow)."""
+    import os
+    import subprocess
+    import tempfile
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "svr_demo")
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory() as tmp:
+        src, prefix = os.path.join(tmp, "img"), os.path.join(tmp, "out")
+        with open(src, "wb") as f:
+            f.write(data)
+        r = subprocess.run([exe, "--png", src, "--dump", prefix], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            return None
+        _tag, w, h = r.stdout.split()[:3]
+        return np.fromfile(prefix + ".rgba", dtype=np.uint8).reshape(int(h), int(w), 4)
+
+
 def load_gltf(path):
     """.glb / .gltf -> scenes.Scene, packed as load_gltf_meshes packs it (src/vk_loader.cpp:162-437).
     The engine's defaults a file can fall back on are appended to the scene's own lists: the last texture
@@ -228,10 +247,13 @@ def load_gltf(path):
             else:
                 bv = doc["bufferViews"][im["bufferView"]]
                 data = buffers[bv["buffer"]][bv.get("byteOffset", 0):bv.get("byteOffset", 0) + bv["byteLength"]]
-            img = Image.open(io.BytesIO(data))
-            if img.mode in ("I;16", "I;16B", "I"):
-                raise ValueError("16-bit greyscale is left to the C++ loader")
-            sc.textures.append(np.ascontiguousarray(np.asarray(img.convert("RGBA"), dtype=np.uint8)))
+            pixels = _host_decode(data)  # the C++ host's decoders: the reference's stb_image, byte for byte
+            if pixels is None:
+                img = Image.open(io.BytesIO(data))
+                if img.mode in ("I;16", "I;16B", "I"):
+                    raise ValueError("16-bit greyscale is left to the C++ loader")
+                pixels = np.ascontiguousarray(np.asarray(img.convert("RGBA"), dtype=np.uint8))
+            sc.textures.append(pixels)
             sc.texture_mips.append(True)
         except Exception:  # the reference substitutes the error checkerboard (src/vk_loader.cpp:226-231)
             failed.append(i)
