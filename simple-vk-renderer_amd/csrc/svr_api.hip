@@ -885,6 +885,8 @@ int svr_bind_targets(SvrContext* ctx, void* color_dev, void* depth_dev) {
 
 int svr_get_targets(SvrContext* ctx, void** color_dev, void** depth_dev) {
   if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  if (int e = use_device(ctx)) return e;
+  if (int e = flush_clear(ctx)) return e;  // the caller is about to look at the memory itself
   if (color_dev) *color_dev = ctx->color;
   if (depth_dev) *depth_dev = ctx->depth;
   return SVR_OK;
