@@ -328,6 +328,42 @@ def test_full_size_properties_4k(hip):
     r.close()
 
 
+def test_full_size_properties_8k_instanced(hip):
+    """BASELINE configs[4] at full size — 7680x4320, the scene x16 instances (4.2 M triangles, 5408 draws,
+    device-flattened) — by properties: the frame does not depend on where cull/sort run (host vs device),
+    nor on how it is cut into bands; every fragment belongs to exactly one band; an identical second frame."""
+    W, H = 7680, 4320
+    cam, inst = S.config5_camera(), S.config5_instances()
+    r, scene, opaque, transparent = T.setup_sponza(hip, W, H, lod=1, tex_size=128, camera=cam, instances=inst)
+    assert len(opaque) + len(transparent) == 5408
+    r.set_option(A.OPT_COUNT_FRAGMENTS, 1)
+    frames, stats = [], []
+    for mode in (1, 2, 1):  # device flatten, host path, device again
+        r.set_option(A.OPT_DEVICE_FLATTEN, mode)
+        r.clear_color((1, 1, 1, 1))
+        r.draw_geometry(scene, opaque, transparent)
+        r.sync()
+        st = r.get_stats()
+        frames.append((r.read_color().copy(), r.read_depth().copy()))
+        stats.append((st.triangle_count, st.drawcall_count, st.culled_draws, st.rasterized_fragments, st.shaded_fragments, st.binned_triangles))
+    assert stats[0] == stats[1] == stats[2]
+    assert stats[0][0] > 3_000_000 and stats[0][3] >= stats[0][4] > W * H // 4
+    for c, d in frames[1:]:
+        assert np.array_equal(c, frames[0][0]) and np.array_equal(d, frames[0][1])
+    assert 0.0 <= frames[0][1].min() and frames[0][1].max() <= 1.0
+    r.set_option(A.OPT_DEVICE_FLATTEN, 0)
+    tot = 0
+    for k in range(8):
+        r.set_scissor(0, k * 540, W, 540)
+        r.clear_color((1, 1, 1, 1))
+        r.draw_geometry(scene, opaque, transparent)
+        r.sync()
+        tot += r.get_stats().rasterized_fragments
+    assert np.array_equal(r.read_color(), frames[0][0]) and np.array_equal(r.read_depth(), frames[0][1])
+    assert tot == stats[0][3]
+    r.close()
+
+
 def test_errors_on_the_hip_library(hip):
     r = hip.create(16, 16)
     with pytest.raises(pkg.SvrError) as ei:
