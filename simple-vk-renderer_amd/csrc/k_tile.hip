@@ -417,14 +417,15 @@ __device__ __forceinline__ uint32_t resolve_record(const FrameParams& P, uint32_
 // of 64: they are applied in queue order by electing, per pixel, the lowest pending lane with ds_min
 // (the result of a min does not depend on lane execution order).
 constexpr uint32_t SORT_CAP = 2048;                       // bins above this are sorted in the global sort arena instead of LDS
+constexpr uint32_t RANK_SORT_MAX = 1024;                  // bins up to this are sorted by counting ranks, larger ones by the bitonic network
 constexpr uint32_t QUEUE_CAP = 128;                       // < 64 carried over + up to 64 new per row step
-constexpr uint32_t WAVE_C_BYTES = 256 * 8 + QUEUE_CAP * 8 + 256 * 4;  // colour band | queue | election slots
+constexpr uint32_t WAVE_C_BYTES = 256 * 8 + QUEUE_CAP * 8 + 256 * 8 + 64 * 16;  // colour band | queue | lane mask per pixel | shaded colours
 constexpr uint32_t PHASE_C_BYTES = 4 * WAVE_C_BYTES + TILE * TILE * 4;  // + the tile's opaque depth bits
 
 template <int FMT, bool INSTR>
 __device__ __forceinline__ void flush_fragments(const FrameParams& P, typename Codec<FMT>::enc_t* col, uint2* q,
-                                                uint32_t* slot, uint32_t& qn, int tx0, int by0, uint32_t lane,
-                                                uint32_t& n_shaded) {
+                                                unsigned long long* mask, float4* s_src, uint32_t& qn, int tx0, int by0,
+                                                uint32_t lane, uint32_t& n_shaded) {
   typedef Codec<FMT> CD;
   uint32_t cnt = min(qn, 64u);
   bool act = lane < cnt;
@@ -436,23 +437,36 @@ __device__ __forceinline__ void flush_fragments(const FrameParams& P, typename C
     src = shade_pixel<false>(P, rec, px, py, nullptr);
     if (INSTR) n_shaded++;
   }
-  bool pending = act;
-  while (__ballot(pending)) {
-    if (pending) atomicMin(&slot[pix], lane);
-    if (pending && slot[pix] == lane) {
-      float4 dst = CD::decode(col[pix]);
+  // Blending is ordered per pixel (C13) and a group of 64 queued fragments often holds many layers of
+  // the same few pixels (a curtain seen edge-on).  Every pixel's fragments are collected as a lane mask
+  // (one LDS atomic), and the lowest lane of each mask blends its pixel's fragments in lane order =
+  // submission order, in registers: one LDS read per layer instead of an election round per layer.
+  if (act) {
+    s_src[lane] = src;
+    atomicOr(&mask[pix], 1ull << lane);
+  }
+  __builtin_amdgcn_wave_barrier();  // LDS operations of a wave retire in order; this pins the compiler's order too
+  unsigned long long mm = act ? mask[pix] : 0ull;
+  if (act && (mm & ((1ull << lane) - 1ull)) == 0ull) {
+    float4 dst = CD::decode(col[pix]);
+    typename CD::enc_t out = col[pix];
+    while (mm) {
+      uint32_t j = (uint32_t)__ffsll((long long)mm) - 1u;
+      mm &= mm - 1ull;
+      float4 sj = s_src[j];
       // enable_blending_additive: rgb = src*ONE + dst*DST_ALPHA, a = src*ONE + dst*ZERO
-      float4 o = make_float4(fmaf(dst.x, dst.w, src.x), fmaf(dst.y, dst.w, src.y), fmaf(dst.z, dst.w, src.z), src.w);
+      float4 o = make_float4(fmaf(dst.x, dst.w, sj.x), fmaf(dst.y, dst.w, sj.y), fmaf(dst.z, dst.w, sj.z), sj.w);
       if (INSTR && P.trace_buf && px == P.trace_x && py == P.trace_y) {
-        (void)shade_pixel<true>(P, rec, px, py, P.trace_buf);
+        (void)shade_pixel<true>(P, q[j].y, px, py, P.trace_buf);
         float* tb = P.trace_buf;
         tb[32] = dst.x; tb[33] = dst.y; tb[34] = dst.z; tb[35] = dst.w;
         tb[36] = o.x; tb[37] = o.y; tb[38] = o.z; tb[39] = o.w;
       }
-      col[pix] = CD::encode(o);
-      slot[pix] = 0xffffffffu;
-      pending = false;
+      out = CD::encode(o);
+      dst = CD::decode(out);  // the attachment holds the rounded value between layers
     }
+    col[pix] = out;
+    mask[pix] = 0ull;
   }
   uint32_t rest = qn - cnt;
   for (uint32_t j = lane; j < rest; j += 64u) {  // lock-step: every read of a step precedes its writes
@@ -465,7 +479,7 @@ __device__ __forceinline__ void flush_fragments(const FrameParams& P, typename C
 template <int FMT, bool INSTR>
 __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, uint32_t bin_base,
                                                      uint32_t n, int tx0, int ty0, const uint32_t* s_z,
-                                                     typename Codec<FMT>::enc_t* col, uint2* q, uint32_t* slot,
+                                                     typename Codec<FMT>::enc_t* col, uint2* q, unsigned long long* mask, float4* s_src,
                                                      uint32_t& n_raster, uint32_t& n_shaded) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const unsigned long long below = (1ull << lane) - 1ull;
@@ -535,7 +549,7 @@ __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4
         if (m) {
           if (pass) q[qn + (uint32_t)__popcll(m & below)] = make_uint2((uint32_t)(t * TILE + colx), ri);
           qn += (uint32_t)__popcll(m);
-          if (qn >= 64u) flush_fragments<FMT, INSTR>(P, col, q, slot, qn, tx0, by0, lane, n_shaded);
+          if (qn >= 64u) flush_fragments<FMT, INSTR>(P, col, q, mask, s_src, qn, tx0, by0, lane, n_shaded);
         }
         f0 += B0;
         f1 += B1;
@@ -543,13 +557,49 @@ __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4
       }
     }
   }
-  while (qn) flush_fragments<FMT, INSTR>(P, col, q, slot, qn, tx0, by0, lane, n_shaded);
+  while (qn) flush_fragments<FMT, INSTR>(P, col, q, mask, s_src, qn, tx0, by0, lane, n_shaded);
 }
 
 // bitonic sort of the bin's (key << 32 | record) words by all 256 threads, written back in place.
+template <uint32_t K>
+__device__ __forceinline__ void rank_and_place(const FrameParams& P, const unsigned long long* s, uint32_t bin_base, uint32_t n) {
+  unsigned long long mine[K];
+  uint32_t rank[K];
+#pragma unroll
+  for (uint32_t k = 0; k < K; k++) {
+    uint32_t i = threadIdx.x + 256u * k;
+    mine[k] = i < n ? s[i] : 0ull;
+    rank[k] = 0;
+  }
+  for (uint32_t j = 0; j < n; j++) {
+    unsigned long long v = s[j];
+#pragma unroll
+    for (uint32_t k = 0; k < K; k++) rank[k] += v < mine[k] ? 1u : 0u;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < K; k++)
+    if (threadIdx.x + 256u * k < n) P.bins[bin_base + rank[k]] = (uint32_t)mine[k];
+}
+
 // s: scratch for the next power of two >= n words — the LDS block for bins up to SORT_CAP, else the tile's span
 // of the global sort arena (fill_kernel reserved it; global memory is coherent inside a workgroup's CU).
 __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned long long* s, uint32_t bin_base, uint32_t n) {
+  if (n <= RANK_SORT_MAX) {
+    // Rank by counting: keys are unique (the record index is their low word), so the number of smaller
+    // keys IS the sorted position.  Every lane reads the same key per step (an LDS broadcast) against its
+    // own <= 4; two barriers in all, where the bitonic network below pays one per compare-exchange step
+    // (55 of them at 1024 entries: 75K cycles for the 590-triangle curtain bins, 23K for 200).
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+      uint32_t ri = P.bins[bin_base + i];
+      s[i] = ((unsigned long long)P.recs[ri].key << 32) | ri;
+    }
+    __syncthreads();
+    if (n <= 256u) rank_and_place<1>(P, s, bin_base, n);
+    else rank_and_place<RANK_SORT_MAX / 256>(P, s, bin_base, n);
+    __threadfence_block();
+    __syncthreads();
+    return;
+  }
   uint32_t np = 64;
   while (np < n) np <<= 1;
   for (uint32_t i = threadIdx.x; i < np; i += 256u) {
@@ -725,10 +775,11 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
     unsigned char* mine = s_c + wave * WAVE_C_BYTES;
     enc_t* col = reinterpret_cast<enc_t*>(mine);
     uint2* q = reinterpret_cast<uint2*>(mine + 256 * 8);
-    uint32_t* slot = reinterpret_cast<uint32_t*>(mine + 256 * 8 + QUEUE_CAP * 8);
-    for (uint32_t i = lane; i < 256u; i += 64u) slot[i] = 0xffffffffu;
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(mine + 256 * 8 + QUEUE_CAP * 8);
+    float4* s_src = reinterpret_cast<float4*>(mine + 256 * 8 + QUEUE_CAP * 8 + 256 * 8);
+    for (uint32_t i = lane; i < 256u; i += 64u) mask[i] = 0ull;
     // (the first barrier inside the scan orders these writes)
-    scan_columns_ordered<FMT, INSTR>(P, s_cov, s_idx, tbase, n_tr, tx0, ty0, s_z, col, q, slot, n_raster, n_shaded);
+    scan_columns_ordered<FMT, INSTR>(P, s_cov, s_idx, tbase, n_tr, tx0, ty0, s_z, col, q, mask, s_src, n_raster, n_shaded);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; k++) {
