@@ -256,7 +256,7 @@ int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint
  * process; results are identical either way).  bit0: tile kernel walks tiles row-major instead of
  * heaviest-first.  bit1: geometry + binning run on the caller's stream instead of overlapping the
  * previous pass's tile stage on an internal stream.  bit2: svr_clear_color runs at once instead of riding in
- * the next pass.
+ * the next pass.  bit3: heavy tiles are rendered by one workgroup instead of four row quarters.
  * SVR_OPT_DEVICE_FLATTEN: where svr_draw_geometry's host half runs — is_visible, the sort and the
  * per-object draw records (src/vk_engine.cpp:1361-1378, 1412-1457).  0 (default): on the device from
  * 2048 objects up, on the host below; 1: always on the device; 2: always on the host.  Same frames

@@ -162,6 +162,9 @@ __global__ __launch_bounds__(256) void offsets_kernel(FrameParams P) {
   }
   base = __shfl(base, 63);
   if (i < n) P.tile_offset[i] = base + inc - v;
+  uint32_t cost = i < P.n_tiles ? tile_cost(v, P.tile_count[P.n_tiles + i]) : 0u;  // fill_kernel's split rule needs the sum
+  for (int off = 32; off > 0; off >>= 1) cost += __shfl_down(cost, off);
+  if (lane == 0 && cost) atomicAdd(&P.counters->cost_sum, cost);
   __syncthreads();
   if (i < P.n_tiles) atomicAdd(&l_cnt[cls], 1u);  // LDS
   __syncthreads();
@@ -193,16 +196,37 @@ __global__ __launch_bounds__(256) void fill_kernel(FrameParams P) {
     if (has) {
       uint32_t slot = l_base[cls] + rank;
       P.tile_order[slot] = t;
-      P.tile_info[2u * slot] = make_uint4(t, P.tile_count[t], P.tile_offset[t], P.tile_count[P.n_tiles + t]);
+      const uint32_t n_op = P.tile_count[t], n_tr = P.tile_count[P.n_tiles + t];
       // a transparent bin too large for the tile kernel's LDS sort gets a span of the global sort arena
       // (next power of two: the bitonic network pads); failing here voids the pass before it draws
-      uint32_t n_tr = P.tile_count[P.n_tiles + t], sort_base = 0;
+      uint32_t sort_base = 0;
       if (n_tr > 2048u) {
         uint32_t np = 1u << (32 - __clz(n_tr - 1u));
         sort_base = atomicAdd(&P.counters->sort_used, np);
         if (sort_base + np > P.sort_cap) atomicOr(&P.counters->overflow, 4u);
       }
-      P.tile_info[2u * slot + 1u] = make_uint4(P.tile_offset[P.n_tiles + t], sort_base, 0u, 0u);
+      // heavy tile: four quarters (svr_device.h SPLIT_*).  Their common sorted transparent list lives in
+      // the sort arena: every quarter writes the same words there, none touches the bin itself.
+      bool split = !(P.tuning & TUNE_NO_SPLIT) && n_tr <= SPLIT_SORT_MAX &&
+                   tile_cost(n_op, n_tr) > max(SPLIT_MIN_COST, P.counters->cost_sum / TILE_SLOTS);
+      uint32_t sp = 0;
+      if (split) {
+        sp = atomicAdd(&P.counters->n_split, 1u);
+        split = sp < SPLIT_MAX;
+      }
+      if (split && n_tr) {
+        sort_base = atomicAdd(&P.counters->sort_used, (n_tr + 1u) >> 1);  // n_tr 32-bit words
+        if (sort_base + ((n_tr + 1u) >> 1) > P.sort_cap) atomicOr(&P.counters->overflow, 4u);
+      }
+      const uint4 i0 = make_uint4(t, n_op, P.tile_offset[t], n_tr);
+      const uint32_t off_tr = P.tile_offset[P.n_tiles + t];
+      if (split)
+        for (uint32_t j = 0; j < 4; j++) {
+          P.tile_info[2u * (4u * sp + j)] = i0;
+          P.tile_info[2u * (4u * sp + j) + 1u] = make_uint4(off_tr, sort_base, 8u * j, 1u);  // z: first row of the quarter
+        }
+      P.tile_info[2u * (SPLIT_EXTRA + slot)] = i0;
+      P.tile_info[2u * (SPLIT_EXTRA + slot) + 1u] = make_uint4(off_tr, sort_base, 0u, split ? 1u : 0u);  // w: "rendered by its quarters"
     }
   }
   const uint32_t n = min(P.counters->n_pairs, P.bin_cap);

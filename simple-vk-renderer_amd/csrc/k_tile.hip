@@ -303,16 +303,31 @@ struct Codec<SVR_COLOR_RGBA8> {
 // its pieces, see resolve_record).
 template <bool INSTR>
 __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov, uint32_t bin_base, uint32_t n,
-                                             unsigned long long* s_depth, int tx0, int ty0, uint32_t& n_raster) {
+                                             unsigned long long* s_depth, int tx0, int ty0, int ry0, int nrows,
+                                             uint32_t& n_raster) {
+  // rows [ry0, ry0 + nrows) of the tile at (tx0, ty0): the whole tile, or one quarter of a split tile
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  // Staging is double-buffered through registers: the next batch's records (two 16-byte pieces per thread,
+  // behind the dependent bin -> record load) are in flight while this batch is walked.  Single-buffered,
+  // ~3K of the ~7.6K cycles a batch of 64 triangles costs were this latency, exposed.
+  static_assert(BATCH * 8 == 512, "two pieces per thread");
+  uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0;
+  {
+    uint32_t cnt = min((uint32_t)BATCH, n);
+    if (threadIdx.x < cnt * 8u) pre0 = reinterpret_cast<const uint4*>(P.recs + P.bins[bin_base + (threadIdx.x >> 3)])[threadIdx.x & 7u];
+    if (threadIdx.x + 256u < cnt * 8u) pre1 = reinterpret_cast<const uint4*>(P.recs + P.bins[bin_base + 32u + (threadIdx.x >> 3)])[threadIdx.x & 7u];
+  }
   for (uint32_t b0 = 0; b0 < n; b0 += BATCH) {
     uint32_t cnt = min((uint32_t)BATCH, n - b0);
     __syncthreads();  // previous batch fully consumed
-    for (uint32_t piece = threadIdx.x; piece < cnt * 8u; piece += 256u) {
-      uint32_t ri = P.bins[bin_base + b0 + (piece >> 3)];
-      s_cov[piece] = reinterpret_cast<const uint4*>(P.recs + ri)[piece & 7u];
-    }
+    if (threadIdx.x < cnt * 8u) s_cov[threadIdx.x] = pre0;
+    if (threadIdx.x + 256u < cnt * 8u) s_cov[threadIdx.x + 256u] = pre1;
     __syncthreads();
+    if (b0 + BATCH < n) {
+      uint32_t nb = b0 + BATCH, ncnt = min((uint32_t)BATCH, n - nb);
+      if (threadIdx.x < ncnt * 8u) pre0 = reinterpret_cast<const uint4*>(P.recs + P.bins[bin_base + nb + (threadIdx.x >> 3)])[threadIdx.x & 7u];
+      if (threadIdx.x + 256u < ncnt * 8u) pre1 = reinterpret_cast<const uint4*>(P.recs + P.bins[bin_base + nb + 32u + (threadIdx.x >> 3)])[threadIdx.x & 7u];
+    }
     // lane i: column count of triangle i inside this tile
     int cx0 = 0, cw = 0;
     if (lane < cnt) {
@@ -321,7 +336,7 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
       int maxx = (int)(int16_t)(h.y & 0xffffu), maxy = (int)(int16_t)(h.y >> 16);
       cx0 = max(minx, tx0);
       int cx1 = min(maxx, tx0 + TILE - 1);
-      int cy0 = max(miny, ty0), cy1 = min(maxy, ty0 + TILE - 1);
+      int cy0 = max(miny, ry0), cy1 = min(maxy, ry0 + nrows - 1);
       cw = (cx1 >= cx0 && cy1 >= cy0) ? cx1 - cx0 + 1 : 0;
     }
     uint32_t inc = (uint32_t)cw;
@@ -334,7 +349,7 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
     // Few columns (a tile under a couple of large triangles): cut every column into 2 or 4 row bands so
     // that all four waves share the walk instead of one wave walking 32 rows per lane.
     const uint32_t sh = total <= 64u ? 2u : (total <= 128u ? 1u : 0u);  // log2(bands)
-    const int band_rows = TILE >> sh;
+    const int band_rows = nrows >> sh;
     const uint32_t items = total << sh;
     for (uint32_t c = wave; c * 64u < items; c += 4u) {
       uint32_t item = c * 64u + lane;
@@ -355,7 +370,7 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
       const uint4* rec = s_cov + i * 8u;
       uint4 h = rec[0];
       int miny = (int)(int16_t)(h.x >> 16), maxy = (int)(int16_t)(h.y >> 16);
-      int y0 = max(miny, ty0 + (int)band * band_rows), y1 = min(maxy, ty0 + (int)band * band_rows + band_rows - 1);
+      int y0 = max(miny, ry0 + (int)band * band_rows), y1 = min(maxy, ry0 + (int)band * band_rows + band_rows - 1);
       if (y0 > y1) continue;
       uint32_t key = h.z, flags = h.w;
       float4 zr = reinterpret_cast<const float4*>(rec)[1];
@@ -417,7 +432,7 @@ __device__ __forceinline__ uint32_t resolve_record(const FrameParams& P, uint32_
 // of 64: they are applied in queue order by electing, per pixel, the lowest pending lane with ds_min
 // (the result of a min does not depend on lane execution order).
 constexpr uint32_t SORT_CAP = 2048;                       // bins above this are sorted in the global sort arena instead of LDS
-constexpr uint32_t RANK_SORT_MAX = 1024;                  // bins up to this are sorted by counting ranks, larger ones by the bitonic network
+constexpr uint32_t RANK_SORT_MAX = 2048;                  // bins up to this (all that fit LDS) are sorted by counting ranks, larger ones by the bitonic network
 constexpr uint32_t QUEUE_CAP = 128;                       // < 64 carried over + up to 64 new per row step
 constexpr uint32_t WAVE_C_BYTES = 256 * 8 + QUEUE_CAP * 8 + 256 * 8 + 64 * 16;  // colour band | queue | lane mask per pixel | shaded colours
 constexpr uint32_t PHASE_C_BYTES = 4 * WAVE_C_BYTES + TILE * TILE * 4;  // + the tile's opaque depth bits
@@ -477,19 +492,20 @@ __device__ __forceinline__ void flush_fragments(const FrameParams& P, typename C
 }
 
 template <int FMT, bool INSTR>
-__device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, uint32_t bin_base,
-                                                     uint32_t n, int tx0, int ty0, const uint32_t* s_z,
+__device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, const uint32_t* order,
+                                                     uint32_t n, int tx0, int ty0, int row0, uint32_t lrpw, const uint32_t* s_z,
                                                      typename Codec<FMT>::enc_t* col, uint2* q, unsigned long long* mask, float4* s_src,
                                                      uint32_t& n_raster, uint32_t& n_shaded) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const unsigned long long below = (1ull << lane) - 1ull;
-  const int by0 = ty0 + 8 * (int)wave, by1 = by0 + 7;  // this wave's rows
+  const int rpw = 1 << lrpw;  // rows per wave: 8, or 2 in a quarter
+  const int by0 = ty0 + row0 + rpw * (int)wave, by1 = by0 + rpw - 1;  // this wave's rows
   uint32_t qn = 0;
   for (uint32_t b0 = 0; b0 < n; b0 += BATCH) {
     uint32_t cnt = min((uint32_t)BATCH, n - b0);
     __syncthreads();
     for (uint32_t piece = threadIdx.x; piece < cnt * 8u; piece += 256u) {
-      uint32_t ri = P.bins[bin_base + b0 + (piece >> 3)];
+      uint32_t ri = order[b0 + (piece >> 3)];
       s_cov[piece] = reinterpret_cast<const uint4*>(P.recs + ri)[piece & 7u];
       if ((piece & 7u) == 0) s_idx[piece >> 3] = ri;
     }
@@ -537,7 +553,7 @@ __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4
       double f1 = fma(c2.y, dx, fma(B1, dy, c5.y));
       double f2 = fma(c3.x, dx, fma(B2, dy, c6.x));
 #pragma unroll 1
-      for (int t = 0; t < 8; t++) {  // the same absolute row by0 + t in every lane
+      for (int t = 0; t < rpw; t++) {  // the same absolute row by0 + t in every lane
         int y = by0 + t;
         bool inside = act && y >= y0 && y <= y1 && f0 >= 0.0 && f1 >= 0.0 && f2 >= 0.0;
         if (INSTR) n_raster += inside ? 1u : 0u;
@@ -562,7 +578,7 @@ __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4
 
 // bitonic sort of the bin's (key << 32 | record) words by all 256 threads, written back in place.
 template <uint32_t K>
-__device__ __forceinline__ void rank_and_place(const FrameParams& P, const unsigned long long* s, uint32_t bin_base, uint32_t n) {
+__device__ __forceinline__ void rank_and_place(const unsigned long long* s, uint32_t* out, uint32_t n) {
   unsigned long long mine[K];
   uint32_t rank[K];
 #pragma unroll
@@ -578,12 +594,15 @@ __device__ __forceinline__ void rank_and_place(const FrameParams& P, const unsig
   }
 #pragma unroll
   for (uint32_t k = 0; k < K; k++)
-    if (threadIdx.x + 256u * k < n) P.bins[bin_base + rank[k]] = (uint32_t)mine[k];
+    if (threadIdx.x + 256u * k < n) out[rank[k]] = (uint32_t)mine[k];
 }
 
 // s: scratch for the next power of two >= n words — the LDS block for bins up to SORT_CAP, else the tile's span
 // of the global sort arena (fill_kernel reserved it; global memory is coherent inside a workgroup's CU).
-__device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned long long* s, uint32_t bin_base, uint32_t n) {
+// out: where the sorted record indices go — the bin itself, or (quarters of a split tile, n <= RANK_SORT_MAX) the
+// tile's words of the sort arena, which all four quarters fill with the same values.
+__device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned long long* s, uint32_t bin_base, uint32_t n,
+                                                uint32_t* out) {
   if (n <= RANK_SORT_MAX) {
     // Rank by counting: keys are unique (the record index is their low word), so the number of smaller
     // keys IS the sorted position.  Every lane reads the same key per step (an LDS broadcast) against its
@@ -594,8 +613,11 @@ __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned l
       s[i] = ((unsigned long long)P.recs[ri].key << 32) | ri;
     }
     __syncthreads();
-    if (n <= 256u) rank_and_place<1>(P, s, bin_base, n);
-    else rank_and_place<RANK_SORT_MAX / 256>(P, s, bin_base, n);
+    if (n <= 256u) rank_and_place<1>(s, out, n);
+    else if (n <= 512u) rank_and_place<2>(s, out, n);
+    else if (n <= 1024u) rank_and_place<4>(s, out, n);
+    else if (n <= 1536u) rank_and_place<6>(s, out, n);
+    else rank_and_place<8>(s, out, n);
     __threadfence_block();
     __syncthreads();
     return;
@@ -627,20 +649,24 @@ __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned l
       __syncthreads();
     }
   }
-  for (uint32_t i = threadIdx.x; i < n; i += 256u) P.bins[bin_base + i] = (uint32_t)s[i];
+  for (uint32_t i = threadIdx.x; i < n; i += 256u) out[i] = (uint32_t)s[i];
   __threadfence_block();
   __syncthreads();
 }
 
-template <int FMT, bool INSTR>
-__device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, unsigned char* s_c) {
+// QUARTER: this workgroup renders 8 rows of a split tile (svr_device.h SPLIT_*).  Its own instantiation, chosen
+// by blockIdx alone: sharing one body with run-time row ranges cost the whole-tile path 20-35 spilled
+// registers and 8-13 % of the frame, and choosing by a flag in tile_info put a dependent load in front of
+// every tile (+2 %).
+template <int FMT, bool INSTR, bool QUARTER, bool SPLIT>
+__device__ __forceinline__ void tile_body(const FrameParams& P, uint32_t launch_slot, uint4* s_cov, uint32_t* s_idx, unsigned char* s_c) {
   typedef Codec<FMT> CD;
   typedef typename CD::enc_t enc_t;
   // Workgroups are dispatched in blockIdx order: walk the tiles heaviest class first (fill_kernel's
   // tile_order).  Tiles are dealt round-robin over the 8 XCDs; a contiguous span per XCD was tried
   // and loses: the heavy rows of the frame all land on one XCD and the other seven idle.
   // One 32-byte scalar load names the tile and its two bins (fill_kernel wrote it in launch order).
-  uint32_t tile, n_op, n_tr, off_op, off_tr, sort_base = 0;
+  uint32_t tile, n_op, n_tr, off_op, off_tr, sort_base = 0, rows = 3u << 8, is_split = 0;
   if (P.tuning & TUNE_NO_TILE_ORDER) {
     tile = blockIdx.x;
     n_op = P.tile_count[tile];
@@ -648,21 +674,27 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
     off_op = P.tile_offset[tile];
     off_tr = P.tile_offset[P.n_tiles + tile];
   } else {
-    uint4 i0 = P.tile_info[2u * blockIdx.x], i1 = P.tile_info[2u * blockIdx.x + 1u];
-    tile = i0.x; n_op = i0.y; off_op = i0.z; n_tr = i0.w; off_tr = i1.x; sort_base = i1.y;
+    uint4 i0 = P.tile_info[2u * launch_slot], i1 = P.tile_info[2u * launch_slot + 1u];
+    tile = i0.x; n_op = i0.y; off_op = i0.z; n_tr = i0.w; off_tr = i1.x; sort_base = i1.y; rows = i1.z; is_split = i1.w;
   }
+  if (SPLIT && !QUARTER && is_split) return;  // a split tile's slot in the ordinary launch order: its quarters head the launch
+  // this workgroup's rows of the tile, row0 .. row0 + nrows - 1; pixels outside them are treated like pixels outside the scissor
+  const int row0 = QUARTER ? (int)(rows & 0xffu) : 0;
+  constexpr uint32_t lrpw = QUARTER ? 1u : 3u;  // log2(rows per wave in phase C)
+  constexpr int nrows = 4 << lrpw;
   uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
   uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   int ox = (int)(P.sx + tx * TILE + (wave & 1u) * 16u), oy = (int)(P.sy + ty * TILE + (wave >> 1) * 16u);
   int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
   int x_end = (int)(P.sx + P.sw), y_end = (int)(P.sy + P.sh);
 
+  const int sub_y0 = (int)(P.sy + ty * TILE) + row0;
   bool pix_ok[4];
   uint32_t zbits[4], keys[4], recs[4], zero4[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
-    pix_ok[k] = px < x_end && py < y_end;
+    pix_ok[k] = px < x_end && py < y_end && (!QUARTER || (uint32_t)(py - sub_y0) < (uint32_t)nrows);
     zbits[k] = 0u;  // depth CLEAR 0.0
     keys[k] = 0u;
     recs[k] = NO_REC;
@@ -678,12 +710,17 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
     unsigned long long* s_depth = reinterpret_cast<unsigned long long*>(s_c);  // 8 KiB of the phase-C block
     int tx0 = (int)(P.sx + tx * TILE), ty0 = (int)(P.sy + ty * TILE);
     for (uint32_t i = threadIdx.x; i < TILE * TILE; i += 256u) s_depth[i] = 0ull;  // ordered by scan_columns' first barrier
-    scan_columns<INSTR>(P, s_cov, off_op, n_op, s_depth, tx0, ty0, n_raster);
+    scan_columns<INSTR>(P, s_cov, off_op, n_op, s_depth, tx0, ty0, QUARTER ? sub_y0 : ty0, nrows, n_raster);
     __syncthreads();
+    // (the pixel's place in the tile is recomputed from the thread index behind a compiler barrier: kept live
+    // across the scan it was spilled to scratch, and the two reloads stood in front of every tile's phase B)
+    uint32_t tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int rx0 = (int)(((tid >> 6) & 1u) * 16u + (tid & 7u)), ry0 = (int)((tid >> 7) * 16u + ((tid >> 3) & 7u));
 #pragma unroll
     for (int k = 0; k < 4; k++) {  // the winners move into the owning lanes' registers
       int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
-      unsigned long long v = s_depth[(py - ty0) * TILE + (px - tx0)];
+      unsigned long long v = s_depth[(ry0 + (k >> 1) * 8) * TILE + rx0 + (k & 1) * 8];
       if ((uint32_t)v != 0u) {
         zbits[k] = (uint32_t)(v >> 32);
         keys[k] = (uint32_t)v;
@@ -759,8 +796,16 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
   if (n_tr) {
     uint32_t tbase = off_tr;
     int tx0 = (int)(P.sx + tx * TILE), ty0 = (int)(P.sy + ty * TILE);
-    if (n_tr <= SORT_CAP) sort_bin_by_key(P, reinterpret_cast<unsigned long long*>(s_c), tbase, n_tr);
-    else sort_bin_by_key(P, P.sort_arena + sort_base, tbase, n_tr);  // rare: a bin too large for LDS
+    const uint32_t* order = P.bins + tbase;
+    if (QUARTER) {  // n_tr <= SORT_CAP: sorted in LDS, written out of place
+      uint32_t* shared_list = reinterpret_cast<uint32_t*>(P.sort_arena + sort_base);
+      sort_bin_by_key(P, reinterpret_cast<unsigned long long*>(s_c), tbase, n_tr, shared_list);
+      order = shared_list;
+    } else if (n_tr <= SORT_CAP) {
+      sort_bin_by_key(P, reinterpret_cast<unsigned long long*>(s_c), tbase, n_tr, P.bins + tbase);
+    } else {
+      sort_bin_by_key(P, P.sort_arena + sort_base, tbase, n_tr, P.bins + tbase);  // rare: a bin too large for LDS
+    }
     uint32_t* s_z = reinterpret_cast<uint32_t*>(s_c + 4 * WAVE_C_BYTES);
 #pragma unroll
     for (int k = 0; k < 4; k++) {  // owners publish colour and opaque depth of their pixels to the row bands
@@ -768,8 +813,8 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
       size_t p = (size_t)py * P.W + (size_t)px;
       enc_t c = enc[k];
       if (!dirty[k] && pix_ok[k]) c = reinterpret_cast<const enc_t*>(P.color)[p];  // colour loadOp LOAD
-      int ry = py - ty0, rx = px - tx0;
-      reinterpret_cast<enc_t*>(s_c + (ry >> 3) * WAVE_C_BYTES)[(ry & 7) * TILE + rx] = c;
+      int ry = py - ty0, rx = px - tx0, rr = ry - row0;
+      if (!QUARTER || (uint32_t)rr < (uint32_t)nrows) reinterpret_cast<enc_t*>(s_c + (rr >> lrpw) * WAVE_C_BYTES)[(rr & ((1 << lrpw) - 1)) * TILE + rx] = c;
       s_z[ry * TILE + rx] = zbits[k];
     }
     unsigned char* mine = s_c + wave * WAVE_C_BYTES;
@@ -779,12 +824,12 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
     float4* s_src = reinterpret_cast<float4*>(mine + 256 * 8 + QUEUE_CAP * 8 + 256 * 8);
     for (uint32_t i = lane; i < 256u; i += 64u) mask[i] = 0ull;
     // (the first barrier inside the scan orders these writes)
-    scan_columns_ordered<FMT, INSTR>(P, s_cov, s_idx, tbase, n_tr, tx0, ty0, s_z, col, q, mask, s_src, n_raster, n_shaded);
+    scan_columns_ordered<FMT, INSTR>(P, s_cov, s_idx, order, n_tr, tx0, ty0, row0, lrpw, s_z, col, q, mask, s_src, n_raster, n_shaded);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      int ry = oy + (k >> 1) * 8 + ly - ty0, rx = ox + (k & 1) * 8 + lx - tx0;
-      enc[k] = reinterpret_cast<const enc_t*>(s_c + (ry >> 3) * WAVE_C_BYTES)[(ry & 7) * TILE + rx];
+      int rr = oy + (k >> 1) * 8 + ly - ty0 - row0, rx = ox + (k & 1) * 8 + lx - tx0;
+      if (!QUARTER || (uint32_t)rr < (uint32_t)nrows) enc[k] = reinterpret_cast<const enc_t*>(s_c + (rr >> lrpw) * WAVE_C_BYTES)[(rr & ((1 << lrpw) - 1)) * TILE + rx];
       dirty[k] = pix_ok[k];
     }
   }
@@ -832,7 +877,7 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
   }
   if (stamps) {
     stamp[4] = clock64();
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0 && row0 == 0)  // of a split tile: its first quarter
       for (int k = 0; k < 4; k++) P.tile_cycles[tile * 4u + k] = (uint32_t)(stamp[k + 1] - stamp[k]);
   }
   if (INSTR) {
@@ -847,12 +892,15 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint4* s_cov, ui
   }
 }
 
-template <int FMT, bool INSTR>
+// SPLIT: the launch is headed by SPLIT_EXTRA slots for the quarters of split tiles.  A kernel of its own: the
+// quarter path merely compiled in costs the whole-tile path 2-3 % (registers, code size), which a pass with
+// more than SPLIT_TILES_MAX tiles — where no tile is worth splitting — need not pay.
+template <int FMT, bool INSTR, bool SPLIT>
 __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
   __shared__ uint4 s_cov[BATCH * 8];
   __shared__ uint32_t s_idx[BATCH];
-  __shared__ __attribute__((aligned(16))) unsigned char s_c[PHASE_C_BYTES];  // phase A depth tile, phase C blocks (20 KiB)
-  static_assert(PHASE_C_BYTES >= SORT_CAP * 8 && PHASE_C_BYTES >= TILE * TILE * 8, "sort scratch and depth tile alias the block");
+  __shared__ __attribute__((aligned(16))) unsigned char s_c[PHASE_C_BYTES];  // phase A depth tile, phase C blocks
+  static_assert(SPLIT_SORT_MAX <= SORT_CAP && PHASE_C_BYTES >= SORT_CAP * 8 && PHASE_C_BYTES >= TILE * TILE * 8, "sort scratch and depth tile alias the block");
 
   // A pass that overflowed a queue is void, and so is everything after it until the host has replayed
   // it (svr_api.hip "the operation log"): the targets stay as they were before the failed pass.
@@ -861,8 +909,15 @@ __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
       *P.poison = 1u;
       __hip_atomic_store(P.host_failed_seq, P.op_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+  } else if (SPLIT) {
+    if (blockIdx.x < SPLIT_EXTRA) {  // the quarters of split tiles, as many as fill_kernel made
+      if (blockIdx.x >= 4u * min(P.counters->n_split, SPLIT_MAX)) return;
+      tile_body<FMT, INSTR, true, true>(P, blockIdx.x, s_cov, s_idx, s_c);
+    } else {
+      tile_body<FMT, INSTR, false, true>(P, blockIdx.x, s_cov, s_idx, s_c);
+    }
   } else {
-    tile_body<FMT, INSTR>(P, s_cov, s_idx, s_c);
+    tile_body<FMT, INSTR, false, false>(P, SPLIT_EXTRA + blockIdx.x, s_cov, s_idx, s_c);
   }
 }
 
@@ -881,20 +936,29 @@ __global__ __launch_bounds__(64) void report_kernel(FrameParams P) {
 // own dispatch packet (hipExtLaunchKernel's stopEvent): a separate hipEventRecord is one more packet
 // for the command processor between two tile kernels.
 void launch_tiles(const FrameParams& P, int color_format, bool count_fragments, hipStream_t s, hipEvent_t start, hipEvent_t done) {
-  dim3 grid(P.n_tiles), block(256);
+  const bool split = !(P.tuning & (TUNE_NO_SPLIT | TUNE_NO_TILE_ORDER));
+  dim3 grid(split ? P.n_tiles + SPLIT_EXTRA : P.n_tiles), block(256);
   const bool report = count_fragments || P.flatten;
   hipEvent_t tile_done = report ? nullptr : done;
+#define SVR_LAUNCH_TILES(FMT, INSTR, SPLIT) hipExtLaunchKernelGGL((tile_kernel<FMT, INSTR, SPLIT>), grid, block, 0, s, start, tile_done, 0, P)
   if (color_format == SVR_COLOR_RGBA16F) {
-    if (count_fragments)
-      hipExtLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA16F, true>), grid, block, 0, s, start, tile_done, 0, P);
-    else
-      hipExtLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA16F, false>), grid, block, 0, s, start, tile_done, 0, P);
+    if (count_fragments) {
+      if (split) SVR_LAUNCH_TILES(SVR_COLOR_RGBA16F, true, true);
+      else SVR_LAUNCH_TILES(SVR_COLOR_RGBA16F, true, false);
+    } else {
+      if (split) SVR_LAUNCH_TILES(SVR_COLOR_RGBA16F, false, true);
+      else SVR_LAUNCH_TILES(SVR_COLOR_RGBA16F, false, false);
+    }
   } else {
-    if (count_fragments)
-      hipExtLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA8, true>), grid, block, 0, s, start, tile_done, 0, P);
-    else
-      hipExtLaunchKernelGGL((tile_kernel<SVR_COLOR_RGBA8, false>), grid, block, 0, s, start, tile_done, 0, P);
+    if (count_fragments) {
+      if (split) SVR_LAUNCH_TILES(SVR_COLOR_RGBA8, true, true);
+      else SVR_LAUNCH_TILES(SVR_COLOR_RGBA8, true, false);
+    } else {
+      if (split) SVR_LAUNCH_TILES(SVR_COLOR_RGBA8, false, true);
+      else SVR_LAUNCH_TILES(SVR_COLOR_RGBA8, false, false);
+    }
   }
+#undef SVR_LAUNCH_TILES
   if (report) hipExtLaunchKernelGGL(report_kernel, dim3(1), dim3(64), 0, s, nullptr, done, 0, P);
 }
 

@@ -331,7 +331,7 @@ int bind_pass_buffers(SvrContext* ctx, FrameParams& P, int set_index) {
   if (int e = set.recs.ensure(((size_t)P.n_tris + ctx->extra_cap) * sizeof(TriRec))) return e;
   if (int e = set.clipq.ensure((size_t)ctx->clip_cap * sizeof(ClipItem))) return e;
   if (int e = set.bigq.ensure(((size_t)P.n_tris + 64) * sizeof(uint32_t))) return e;
-  if (int e = set.tiles.ensure(TILE_HEAD_BYTES + ((size_t)P.n_tiles * 13 + 8) * sizeof(uint32_t))) return e;
+  if (int e = set.tiles.ensure(TILE_HEAD_BYTES + ((size_t)P.n_tiles * 13 + 8 + (size_t)SPLIT_EXTRA * 8) * sizeof(uint32_t))) return e;
   if (int e = set.bins.ensure((size_t)ctx->bin_cap * sizeof(uint32_t))) return e;
   if (int e = set.pairs.ensure((size_t)ctx->bin_cap * 12)) return e;
   if (int e = set.sorta.ensure((size_t)ctx->bin_cap * 2 * sizeof(unsigned long long))) return e;
@@ -345,7 +345,7 @@ int bind_pass_buffers(SvrContext* ctx, FrameParams& P, int set_index) {
   P.tile_count = (uint32_t*)((char*)set.tiles.p + TILE_HEAD_BYTES);
   P.tile_offset = P.tile_count + (((size_t)P.n_tiles * 2 + 3) & ~(size_t)3);  // 16-byte aligned
   P.tile_info = (uint4*)(P.tile_offset + (((size_t)P.n_tiles * 2 + 3) & ~(size_t)3));  // 8 words per tile
-  P.tile_order = (uint32_t*)P.tile_info + (size_t)P.n_tiles * 8;
+  P.tile_order = (uint32_t*)P.tile_info + ((size_t)P.n_tiles + SPLIT_EXTRA) * 8;  // the quarters of split tiles head tile_info
   P.pairs = (uint2*)set.pairs.p;
   P.pair_slot = (uint32_t*)((char*)set.pairs.p + (size_t)ctx->bin_cap * 8);
   P.bins = (uint32_t*)set.bins.p;
@@ -658,6 +658,7 @@ int fill_frame_params(SvrContext* ctx, const SvrSceneData* scene, uint64_t n_tri
   P.trace_y = ctx->trace_y;
   P.trace_buf = (ctx->instrument && ctx->trace_x >= 0) ? (float*)ctx->d_trace.p : nullptr;
   P.tuning = ctx->tuning;
+  if (P.n_tiles > SPLIT_TILES_MAX) P.tuning |= TUNE_NO_SPLIT;  // svr_device.h: no tile of such a pass is worth splitting
   P.tile_cycles = nullptr;
   if (ctx->tile_cycles) {
     if (int e = ctx->d_tile_cycles.ensure((size_t)P.n_tiles * 16)) return e;

@@ -27,6 +27,24 @@ constexpr uint32_t F_TRANSPARENT = 256u;
 constexpr uint32_t TUNE_NO_TILE_ORDER = 1u;   // tile kernel walks tiles row-major instead of heaviest-first
 constexpr uint32_t TUNE_NO_LAZY_CLEAR = 4u;   // svr_clear_color runs its own kernel at once instead of riding in the next pass
 constexpr uint32_t TUNE_NO_PIPELINE = 2u;     // geometry+binning on the caller's stream too (no overlap between passes)
+constexpr uint32_t TUNE_NO_SPLIT = 8u;        // heavy tiles are not cut into four row quarters
+
+// A heavy tile is rendered by FOUR workgroups, one per 8 rows (tile kernel "quarters").  The slowest tile
+// bounds the tile kernel however many CUs are idle, and ordered blending makes a tile with a deep transparent
+// bin the slowest by far (a curtain seen edge-on: 1270 triangles in a 1080p tile, 400K of its 495K cycles,
+// where the chip's mean load per workgroup slot is 93K) — all the more when the frame is cut into the row
+// bands of a multi-GPU run.  1920x1080: 0.214 -> 0.141 ms; one eighth of a 4K frame: 0.150 -> 0.092 ms.
+// A quarter repeats the tile's per-triangle staging and its sort, so splitting costs total work: a tile is
+// split only when its estimated cost (tile_cost: thousands of cycles, fitted to SVR_OPT_TILE_CYCLES
+// readings) exceeds SPLIT_MIN_COST and the pass's mean load per workgroup slot.  The four quarters of every
+// split tile head the launch (blockIdx < SPLIT_EXTRA; unclaimed slots return at once).
+constexpr uint32_t SPLIT_MAX = 256;            // tiles split per pass at most (first come, first served)
+constexpr uint32_t SPLIT_EXTRA = 4 * SPLIT_MAX;
+constexpr uint32_t SPLIT_MIN_COST = 100;
+constexpr uint32_t SPLIT_TILES_MAX = 4096;     // passes over more tiles run the tile kernel built without the quarter path
+constexpr uint32_t TILE_SLOTS = 1024;          // 256 CUs x 4 resident tile workgroups
+__host__ __device__ inline uint32_t tile_cost(uint32_t n_op, uint32_t n_tr) { return 40u + (n_op >> 3) + n_tr - (n_tr >> 2); }
+constexpr uint32_t SPLIT_SORT_MAX = 2048;      // quarters sort in LDS, out of place (k_tile.hip SORT_CAP): larger transparent bins stay whole
 
 // One draw call (RenderObject after cull+sort), 128 bytes.
 struct DrawDesc {
@@ -117,7 +135,8 @@ struct Counters {
   uint32_t n_pairs;        // (bin, record) pairs appended so far (keeps counting past pair capacity)
   uint32_t n_pairs_setup;  // n_pairs when the setup kernel had finished (snapshot taken by clip_kernel)
   uint32_t sort_used;      // words of the sort arena handed out to transparent bins too large for an LDS sort
-  unsigned long long pad[1];
+  uint32_t n_split;        // tiles fill_kernel cut into quarters (keeps counting past SPLIT_MAX)
+  uint32_t cost_sum;       // sum of tile_cost over the pass's tiles (offsets_kernel)
   // device flatten (k_flatten.hip): what the host only knows upper bounds of
   uint32_t flat_draws;     // draws after culling (visible opaque + transparent)
   uint32_t flat_tris;      // their triangles

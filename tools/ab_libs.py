@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--frames", type=int, default=40)
     ap.add_argument("--tuning", type=int, default=0)
+    ap.add_argument("--stages", action="store_true")
     args = ap.parse_args()
     pkg = g.load_package()
     import torch  # noqa: F401  (one HIP runtime per process: torch's is loaded first)
@@ -56,6 +57,19 @@ def main():
     for i, (path, *_rest) in enumerate(ctx):
         a = np.array(res[i])
         print(f"{path}: median {np.median(a):.4f} min {a.min():.4f} max {a.max():.4f} ms/frame")
+    if args.stages:  # per-stage kernel times (events on every stage: the pipeline is perturbed, compare like with like)
+        for path, r, opaque, transparent in ctx:
+            r.set_option(A.OPT_KERNEL_TIMING, 2)
+            acc = []
+            for _ in range(5):
+                for _ in range(20):
+                    r.clear_color((1, 1, 1, 1))
+                    r.draw_geometry(scene, opaque, transparent)
+                r.sync()
+                st = r.get_stats()
+                acc.append((st.geometry_ms, st.binning_ms, st.tile_ms))
+            r.set_option(A.OPT_KERNEL_TIMING, 0)
+            print(f"{path}: geometry/binning/tile median {np.median(np.array(acc), axis=0).round(4).tolist()} ms")
 
 
 if __name__ == "__main__":

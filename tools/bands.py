@@ -1,0 +1,83 @@
+"""Developer tool: what one GPU of an N-GPU run has to do, measured on one GPU.
+
+Rank r of N renders the rows [r*H/N, (r+1)*H/N) (dist.py); this times every band of N = 1, 2, 4, 8 in
+turn on the one GPU present (scissor = the band, present of the band included, no gather) and prints
+the slowest band per N: the frame rate an N-GPU run cannot exceed however fast the gather is.
+
+    python tools/bands.py [--frames 200]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--instances", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--stages", action="store_true", help="also print per-stage kernel times (adds events to the stream)")
+    args = ap.parse_args()
+    import torch
+    pkg = g.load_package()
+    hip = pkg.load_product_library()
+    S, A = pkg.scenes, pkg.abi
+    sc = S.sponza_like(lod=1, tex_size=1024)
+    W, H = args.width, args.height
+    r = hip.create(W, H)
+    handles = sc.upload(r)
+    inst = S.config5_instances() if args.instances == 16 else None
+    opaque, transparent = sc.render_objects(handles, instance_transforms=inst)
+    pos, pitch, yaw = S.config5_camera() if args.instances == 16 else S.config3_camera()
+    scene = S.scene_data_struct(pos, pitch, yaw, W, H)
+    swap = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+
+    def frame(y0, rows):
+        r.clear_color((1, 1, 1, 1))
+        r.draw_geometry(scene, opaque, transparent)
+        r.copy_to_swapchain(swap.data_ptr(), W, H, A.SWAPCHAIN_B8G8R8A8)
+
+    base = None
+    for n in (1, 2, 4, 8):
+        band = (H + n - 1) // n
+        per = []
+        for rk in range(n):
+            y0 = rk * band
+            rows = max(0, min(band, H - y0))
+            r.set_scissor(0, y0, W, rows)
+            r.set_option(A.OPT_KERNEL_TIMING, 0)
+            for _ in range(10):
+                frame(y0, rows)
+            r.sync()
+            t0 = time.perf_counter()
+            for _ in range(args.frames):
+                frame(y0, rows)
+            r.sync()
+            ms = (time.perf_counter() - t0) / args.frames * 1e3
+            stage = ""
+            if args.stages:
+                r.set_option(A.OPT_KERNEL_TIMING, 2)
+                for _ in range(20):
+                    frame(y0, rows)
+                r.sync()
+                st = r.get_stats()
+                stage = f" (geometry {st.geometry_ms:.3f} binning {st.binning_ms:.3f} tile {st.tile_ms:.3f})"
+            per.append(ms)
+            print(f"  N={n} band {rk}: rows {y0}..{y0 + rows}: {ms:.4f} ms/frame{stage}", flush=True)
+        worst, mean = max(per), float(np.mean(per))
+        if base is None:
+            base = worst
+        print(f"N={n}: slowest band {worst:.4f} ms, mean {mean:.4f} ms -> at most {base / worst:.2f}x of N=1 "
+              f"({base / worst / n * 100:.0f} % efficiency before the gather)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
