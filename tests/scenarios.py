@@ -314,7 +314,15 @@ SCENARIOS = {
     "soup_scissor": lambda lib: random_soup(lib, seed=5, scissor=(13, 21, 101, 37)),
     "soup_odd_size": lambda lib: random_soup(lib, w=67, h=35, seed=9, n_tris=300),
     "transparent_stack_40": lambda lib: transparent_stack(lib, 40, jitter=0.05),
+    # 2 * layers transparent triangles in one tile: from 100 layers up the tile is split into row quarters, and the
+    # counting-rank sort runs with 1, 2, 4, 6 or 8 keys per thread
+    "transparent_stack_100": lambda lib: transparent_stack(lib, 100, jitter=0.04),
+    "transparent_stack_230": lambda lib: transparent_stack(lib, 230, jitter=0.03, seed=5),
+    "transparent_stack_450": lambda lib: transparent_stack(lib, 450, jitter=0.02, seed=6),
     "transparent_stack_700": lambda lib: transparent_stack(lib, 700, jitter=0.02),
+    "transparent_stack_1000": lambda lib: transparent_stack(lib, 1000, jitter=0.01, seed=8),
+    # ~1000 opaque triangles per tile: split by the opaque term of the cost alone
+    "soup_dense_split": lambda lib: random_soup(lib, w=96, h=64, seed=13, n_tris=6000, transparent_every=7),
     "transparent_stack_1300_fallback": lambda lib: transparent_stack(lib, 1300),
     "ragged": ragged_draws,
     "empty": empty_frame,

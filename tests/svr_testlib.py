@@ -89,7 +89,8 @@ def setup_sponza(lib, width, height, lod=8, tex_size=64, color_format=0, window=
 
 
 def render_sponza(lib, width, height, lod=8, tex_size=64, color_format=0, scissor=None, camera=None,
-                  instances=None, threads=None, instrument=False, trace=None, queue_caps=None, device_flatten=None):
+                  instances=None, threads=None, instrument=False, trace=None, queue_caps=None, device_flatten=None,
+                  tuning=None):
     """mesh.vert/mesh.frag over the synthetic atrium (BASELINE configs 3-5 at reduced size)."""
     r, scene, opaque, transparent = setup_sponza(lib, width, height, lod, tex_size, color_format,
                                                  camera=camera, instances=instances)
@@ -100,6 +101,8 @@ def render_sponza(lib, width, height, lod=8, tex_size=64, color_format=0, scisso
         r.set_option(5, queue_caps)  # SVR_OPT_QUEUE_CAPS
     if device_flatten is not None:
         r.set_option(6, device_flatten)  # SVR_OPT_DEVICE_FLATTEN
+    if tuning is not None:
+        r.set_option(4, tuning)  # SVR_OPT_TUNING
     if trace:
         r.trace_pixel(*trace)
     r.clear_color((1, 1, 1, 1))

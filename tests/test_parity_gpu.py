@@ -228,6 +228,17 @@ def test_scissor_bands_tile_the_frame(hip, oracle):
         assert np.all(band["depth"][:y0] == 0) and np.all(band["depth"][y1:] == 0)
 
 
+def test_split_tiles_change_nothing(hip):
+    """SVR_OPT_TUNING bit 3 keeps heavy tiles whole; the quarters of split tiles give the same frame.  (At this size
+    the curtain tiles hold hundreds of transparent triangles and the pass's mean load per slot is small: they split.)"""
+    a = T.render_sponza(hip, 960, 540, lod=1, tex_size=128, instrument=True)
+    b = T.render_sponza(hip, 960, 540, lod=1, tex_size=128, instrument=True, tuning=8)
+    assert_same(a, b, "split vs whole tiles")
+    c = T.render_sponza(hip, 960, 540, lod=1, tex_size=128, scissor=(0, 100, 960, 211))
+    d = T.render_sponza(hip, 960, 540, lod=1, tex_size=128, scissor=(0, 100, 960, 211), tuning=8)
+    assert np.array_equal(c["color"], d["color"]) and np.array_equal(c["depth"], d["depth"])
+
+
 def test_config5_instanced_reduced(hip, oracle):
     inst = S.config5_instances()
     cam = S.config5_camera()
