@@ -659,13 +659,13 @@ __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned l
 // registers and 8-13 % of the frame, and choosing by a flag in tile_info put a dependent load in front of
 // every tile (+2 %).
 template <int FMT, bool INSTR, bool QUARTER, bool SPLIT>
-__device__ __forceinline__ void tile_body(const FrameParams& P, uint32_t launch_slot, uint4* s_cov, uint32_t* s_idx, unsigned char* s_c) {
+__device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, const uint4 i1, uint4* s_cov, uint32_t* s_idx, unsigned char* s_c) {
   typedef Codec<FMT> CD;
   typedef typename CD::enc_t enc_t;
   // Workgroups are dispatched in blockIdx order: walk the tiles heaviest class first (fill_kernel's
   // tile_order).  Tiles are dealt round-robin over the 8 XCDs; a contiguous span per XCD was tried
   // and loses: the heavy rows of the frame all land on one XCD and the other seven idle.
-  // One 32-byte scalar load names the tile and its two bins (fill_kernel wrote it in launch order).
+  // i0, i1: the launch slot's 32 bytes of tile_info (the tile and its two bins, written by fill_kernel in launch order).
   uint32_t tile, n_op, n_tr, off_op, off_tr, sort_base = 0, rows = 3u << 8, is_split = 0;
   if (P.tuning & TUNE_NO_TILE_ORDER) {
     tile = blockIdx.x;
@@ -674,7 +674,6 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, uint32_t launch_
     off_op = P.tile_offset[tile];
     off_tr = P.tile_offset[P.n_tiles + tile];
   } else {
-    uint4 i0 = P.tile_info[2u * launch_slot], i1 = P.tile_info[2u * launch_slot + 1u];
     tile = i0.x; n_op = i0.y; off_op = i0.z; n_tr = i0.w; off_tr = i1.x; sort_base = i1.y; rows = i1.z; is_split = i1.w;
   }
   if (SPLIT && !QUARTER && is_split) return;  // a split tile's slot in the ordinary launch order: its quarters head the launch
@@ -902,22 +901,39 @@ __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
   __shared__ __attribute__((aligned(16))) unsigned char s_c[PHASE_C_BYTES];  // phase A depth tile, phase C blocks
   static_assert(SPLIT_SORT_MAX <= SORT_CAP && PHASE_C_BYTES >= SORT_CAP * 8 && PHASE_C_BYTES >= TILE * TILE * 8, "sort scratch and depth tile alias the block");
 
+  // Everything the workgroup needs before it can start comes in ONE round of scalar loads: the failure flags
+  // and the launch slot's tile_info.  (Written as plain loads they compiled to a chain of four round trips
+  // — flags, branch, tile id by a vector load, the other fields by a second one — in front of every tile's
+  // bin -> record chain: ~2 K of a light tile's 33 K cycles.)  Constant address space = scalar loads; all of
+  // it was written by earlier kernels.
+  const uint32_t slot = SPLIT ? blockIdx.x : SPLIT_EXTRA + blockIdx.x;
+  typedef const __attribute__((address_space(4))) uint32_t* const_words;
+  const_words ti = (const_words)(const void*)P.tile_info + 8u * slot;
+  const_words cnt = (const_words)(const void*)P.counters;
+  uint32_t w0 = ti[0], w1 = ti[1], w2 = ti[2], w3 = ti[3], w4 = ti[4], w5 = ti[5], w6 = ti[6], w7 = ti[7];
+  uint32_t overflow = cnt[offsetof(Counters, overflow) / 4], n_split = cnt[offsetof(Counters, n_split) / 4];
+  uint32_t poison = *(const_words)(const void*)P.poison;
+  // (pins all of the loads in front of the first branch: left alone, the compiler sinks the tile_info loads
+  // behind the flags' round trip)
+  asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3), "+s"(w4), "+s"(w5), "+s"(w6), "+s"(w7), "+s"(overflow), "+s"(poison), "+s"(n_split));
+  const uint4 i0 = make_uint4(w0, w1, w2, w3), i1 = make_uint4(w4, w5, w6, w7);
+
   // A pass that overflowed a queue is void, and so is everything after it until the host has replayed
   // it (svr_api.hip "the operation log"): the targets stay as they were before the failed pass.
-  if (P.counters->overflow | *P.poison) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && *P.poison == 0u) {  // the first failure: flag + tell the host which pass
+  if (overflow | poison) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && poison == 0u) {  // the first failure: flag + tell the host which pass
       *P.poison = 1u;
       __hip_atomic_store(P.host_failed_seq, P.op_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   } else if (SPLIT) {
     if (blockIdx.x < SPLIT_EXTRA) {  // the quarters of split tiles, as many as fill_kernel made
-      if (blockIdx.x >= 4u * min(P.counters->n_split, SPLIT_MAX)) return;
-      tile_body<FMT, INSTR, true, true>(P, blockIdx.x, s_cov, s_idx, s_c);
+      if (blockIdx.x >= 4u * min(n_split, SPLIT_MAX)) return;
+      tile_body<FMT, INSTR, true, true>(P, i0, i1, s_cov, s_idx, s_c);
     } else {
-      tile_body<FMT, INSTR, false, true>(P, blockIdx.x, s_cov, s_idx, s_c);
+      tile_body<FMT, INSTR, false, true>(P, i0, i1, s_cov, s_idx, s_c);
     }
   } else {
-    tile_body<FMT, INSTR, false, false>(P, SPLIT_EXTRA + blockIdx.x, s_cov, s_idx, s_c);
+    tile_body<FMT, INSTR, false, false>(P, i0, i1, s_cov, s_idx, s_c);
   }
 }
 
