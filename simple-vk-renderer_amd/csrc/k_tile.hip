@@ -504,10 +504,22 @@ __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4
   for (uint32_t b0 = 0; b0 < n; b0 += BATCH) {
     uint32_t cnt = min((uint32_t)BATCH, n - b0);
     __syncthreads();
-    for (uint32_t piece = threadIdx.x; piece < cnt * 8u; piece += 256u) {
-      uint32_t ri = order[b0 + (piece >> 3)];
-      s_cov[piece] = reinterpret_cast<const uint4*>(P.recs + ri)[piece & 7u];
-      if ((piece & 7u) == 0) s_idx[piece >> 3] = ri;
+    {  // a thread's two pieces: both indices first, then both records — two round trips per batch, not four
+      const uint32_t t0 = threadIdx.x >> 3, pc = threadIdx.x & 7u;
+      uint32_t ri0 = 0, ri1 = 0;
+      if (t0 < cnt) ri0 = order[b0 + t0];
+      if (t0 + 32u < cnt) ri1 = order[b0 + 32u + t0];
+      uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+      if (t0 < cnt) r0 = reinterpret_cast<const uint4*>(P.recs + ri0)[pc];
+      if (t0 + 32u < cnt) r1 = reinterpret_cast<const uint4*>(P.recs + ri1)[pc];
+      if (t0 < cnt) {
+        s_cov[threadIdx.x] = r0;
+        if (pc == 0) s_idx[t0] = ri0;
+      }
+      if (t0 + 32u < cnt) {
+        s_cov[threadIdx.x + 256u] = r1;
+        if (pc == 0) s_idx[t0 + 32u] = ri1;
+      }
     }
     __syncthreads();
     int cx0 = 0, cw = 0;
