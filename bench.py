@@ -200,11 +200,11 @@ def main():
         # HBM bytes per launch of that kernel from the PMC counters cannot be collected from inside this
         # process; the committed rocprofv3 --pmc summary of this very command (1 GPU, default size) is quoted
         traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_g_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_h_traffic.json")
         if world == 1 and not args.gltf and (W, H, args.instances, args.lod, args.tex_size) == (3840, 2160, 1, 1, 1024) and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic, traffic_source = tj["traffic_bytes_per_launch"], "profiles/r01_g_traffic.json: " + tj["correction"]
+            traffic, traffic_source = tj["traffic_bytes_per_launch"], "profiles/r01_h_traffic.json: " + tj["correction"]
         achieved = tile_bytes / tile_s / 1e9 if tile_s > 0 else 0.0
         out = {
             "metric": "shaded fragments/s", "value": shaded * fps, "unit": "fragments/s",

@@ -60,6 +60,7 @@ def main():
             t0 = time.perf_counter()
             for _ in range(args.frames):
                 frame(y0, rows)
+            host_ms = (time.perf_counter() - t0) / args.frames * 1e3  # the host's share: it must stay below the GPU's
             r.sync()
             ms = (time.perf_counter() - t0) / args.frames * 1e3
             stage = ""
@@ -71,7 +72,7 @@ def main():
                 st = r.get_stats()
                 stage = f" (geometry {st.geometry_ms:.3f} binning {st.binning_ms:.3f} tile {st.tile_ms:.3f})"
             per.append(ms)
-            print(f"  N={n} band {rk}: rows {y0}..{y0 + rows}: {ms:.4f} ms/frame{stage}", flush=True)
+            print(f"  N={n} band {rk}: rows {y0}..{y0 + rows}: {ms:.4f} ms/frame (host enqueue {host_ms:.4f}){stage}", flush=True)
         worst, mean = max(per), float(np.mean(per))
         if base is None:
             base = worst
