@@ -588,52 +588,97 @@ __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4
   while (qn) flush_fragments<FMT, INSTR>(P, col, q, mask, s_src, qn, tx0, by0, lane, n_shaded);
 }
 
-// bitonic sort of the bin's (key << 32 | record) words by all 256 threads, written back in place.
-template <uint32_t K>
-__device__ __forceinline__ void rank_and_place(const unsigned long long* s, uint32_t* out, uint32_t n) {
-  unsigned long long mine[K];
-  uint32_t rank[K];
+// Rank by counting: with unique keys the number of smaller keys IS the sorted position.  Every lane reads the
+// same key per step (an LDS broadcast) against its own <= 8; a handful of barriers in all, where the bitonic
+// network below pays one per compare-exchange step (55 of them at 1024 entries: 75K cycles for the
+// 590-triangle curtain bins).
+// The 32-bit submission keys alone are unique unless the clipper's pieces of one triangle share a tile;
+// the rank loop runs on them (a 64-bit compare issues at half rate), every element then claims its rank
+// in an LDS table, and a claim that did not stick means a tie: the (rare) bin is ranked again on
+// (key, record index) words, which are always unique — the order must not depend on which workgroup
+// sorts, the quarters of a split tile all write the same list.
+template <uint32_t K, typename KeyT>
+__device__ __forceinline__ void count_ranks(const KeyT* s, uint32_t n, const KeyT (&mine)[K], uint32_t (&rank)[K]) {
 #pragma unroll
-  for (uint32_t k = 0; k < K; k++) {
-    uint32_t i = threadIdx.x + 256u * k;
-    mine[k] = i < n ? s[i] : 0ull;
-    rank[k] = 0;
-  }
+  for (uint32_t k = 0; k < K; k++) rank[k] = 0;
   for (uint32_t j = 0; j < n; j++) {
-    unsigned long long v = s[j];
+    KeyT v = s[j];
 #pragma unroll
     for (uint32_t k = 0; k < K; k++) rank[k] += v < mine[k] ? 1u : 0u;
   }
-#pragma unroll
-  for (uint32_t k = 0; k < K; k++)
-    if (threadIdx.x + 256u * k < n) out[rank[k]] = (uint32_t)mine[k];
 }
 
-// s: scratch for the next power of two >= n words — the LDS block for bins up to SORT_CAP, else the tile's span
-// of the global sort arena (fill_kernel reserved it; global memory is coherent inside a workgroup's CU).
+template <uint32_t K>
+__device__ __forceinline__ void rank_sort(const FrameParams& P, unsigned char* lds, uint32_t bin_base, uint32_t n, uint32_t* out) {
+  uint32_t* k32 = reinterpret_cast<uint32_t*>(lds);         // [n] keys
+  uint32_t* claim = k32 + RANK_SORT_MAX;                     // [n] element that owns each rank
+  uint32_t ri[K], key[K], rank[K];
+#pragma unroll
+  for (uint32_t k = 0; k < K; k++) {
+    uint32_t i = threadIdx.x + 256u * k;
+    ri[k] = i < n ? P.bins[bin_base + i] : 0u;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < K; k++) {
+    uint32_t i = threadIdx.x + 256u * k;
+    key[k] = i < n ? P.recs[ri[k]].key : 0u;
+    if (i < n) k32[i] = key[k];
+  }
+  __syncthreads();
+  count_ranks<K, uint32_t>(k32, n, key, rank);
+#pragma unroll
+  for (uint32_t k = 0; k < K; k++) {
+    uint32_t i = threadIdx.x + 256u * k;
+    if (i < n) claim[rank[k]] = i;
+  }
+  __syncthreads();
+  bool lost = false;
+#pragma unroll
+  for (uint32_t k = 0; k < K; k++) {
+    uint32_t i = threadIdx.x + 256u * k;
+    lost = lost || (i < n && claim[rank[k]] != i);
+  }
+  if (__syncthreads_or(lost)) {  // equal keys in the bin: rank (key, record index) instead
+    unsigned long long* k64 = reinterpret_cast<unsigned long long*>(lds);
+    unsigned long long wide[K];
+#pragma unroll
+    for (uint32_t k = 0; k < K; k++) {
+      uint32_t i = threadIdx.x + 256u * k;
+      wide[k] = ((unsigned long long)key[k] << 32) | ri[k];
+      if (i < n) k64[i] = wide[k];
+    }
+    __syncthreads();
+    count_ranks<K, unsigned long long>(k64, n, wide, rank);
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < K; k++)
+    if (threadIdx.x + 256u * k < n) out[rank[k]] = ri[k];
+}
+
+// s: scratch — the LDS block (>= 16 KiB) for bins up to SORT_CAP, else the tile's span of the global sort arena,
+// the next power of two >= n words (fill_kernel reserved it; global memory is coherent inside a workgroup's CU).
 // out: where the sorted record indices go — the bin itself, or (quarters of a split tile, n <= RANK_SORT_MAX) the
 // tile's words of the sort arena, which all four quarters fill with the same values.
 __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned long long* s, uint32_t bin_base, uint32_t n,
                                                 uint32_t* out) {
   if (n <= RANK_SORT_MAX) {
-    // Rank by counting: keys are unique (the record index is their low word), so the number of smaller
-    // keys IS the sorted position.  Every lane reads the same key per step (an LDS broadcast) against its
-    // own <= 4; two barriers in all, where the bitonic network below pays one per compare-exchange step
-    // (55 of them at 1024 entries: 75K cycles for the 590-triangle curtain bins, 23K for 200).
-    for (uint32_t i = threadIdx.x; i < n; i += 256u) {
-      uint32_t ri = P.bins[bin_base + i];
-      s[i] = ((unsigned long long)P.recs[ri].key << 32) | ri;
+    unsigned char* lds = reinterpret_cast<unsigned char*>(s);
+    switch ((n + 255u) >> 8) {
+      case 0:
+      case 1: rank_sort<1>(P, lds, bin_base, n, out); break;
+      case 2: rank_sort<2>(P, lds, bin_base, n, out); break;
+      case 3: rank_sort<3>(P, lds, bin_base, n, out); break;
+      case 4: rank_sort<4>(P, lds, bin_base, n, out); break;
+      case 5: rank_sort<5>(P, lds, bin_base, n, out); break;
+      case 6: rank_sort<6>(P, lds, bin_base, n, out); break;
+      case 7: rank_sort<7>(P, lds, bin_base, n, out); break;
+      default: rank_sort<8>(P, lds, bin_base, n, out); break;
     }
-    __syncthreads();
-    if (n <= 256u) rank_and_place<1>(s, out, n);
-    else if (n <= 512u) rank_and_place<2>(s, out, n);
-    else if (n <= 1024u) rank_and_place<4>(s, out, n);
-    else if (n <= 1536u) rank_and_place<6>(s, out, n);
-    else rank_and_place<8>(s, out, n);
     __threadfence_block();
     __syncthreads();
     return;
   }
+  // bitonic sort of the bin's (key << 32 | record) words by all 256 threads
   uint32_t np = 64;
   while (np < n) np <<= 1;
   for (uint32_t i = threadIdx.x; i < np; i += 256u) {

@@ -273,6 +273,25 @@ def transparent_stack(lib, n_layers, size=48, jitter=0.0, seed=21):
     return rig.finish()
 
 
+def transparent_stack_clipped(lib, n_layers=120, size=48):
+    """Transparent quads that cross the z = w plane: the clipper cuts every triangle into a fan of pieces with
+    the parent's submission key, and tiles on the cut hold several pieces of one triangle — equal sort keys
+    in one (split) tile's transparent bin."""
+    rig = Rig(lib, size, size, background=(0.0, 0.0, 0.0, 1))
+    verts, idx = [], []
+    for i in range(n_layers):
+        zl, zr = 0.15 + 0.004 * (i % 9), 1.5 + 0.01 * (i % 7)  # left edge inside, right edge beyond the plane
+        y0 = -0.9 + 0.002 * (i % 5)
+        c = (0.004 + 0.003 * (i % 5), 0.002 * (i % 3), 0.001 * (i % 7), 1)
+        pos = [(-0.9, y0, zl), (0.9, y0, zr), (0.9, 0.9, zr), (-0.9, 0.9, zl)]
+        verts.append(make_vertices(pos, [(0, 1, 0)] * 4, [(0, 0), (1, 0), (1, 1), (0, 1)], [c] * 4))
+        idx.append(QUAD_IDX + 4 * i)
+    mesh = rig.r.upload_mesh(np.concatenate(idx), np.concatenate(verts))
+    mt = rig.material(transparent=True)
+    rig.draw(identity_scene(ambient=0.0, sun=(0, 1, 0, 1)), [], [render_object(mesh, mt, 0, 6 * n_layers)])
+    return rig.finish()
+
+
 def ragged_draws(lib, size=48):
     """index_count not a multiple of 3, zero-length draws, an empty opaque list entry order."""
     rig = Rig(lib, size, size)
@@ -324,6 +343,7 @@ SCENARIOS = {
     # ~1000 opaque triangles per tile: split by the opaque term of the cost alone
     "soup_dense_split": lambda lib: random_soup(lib, w=96, h=64, seed=13, n_tris=6000, transparent_every=7),
     "transparent_stack_1300_fallback": lambda lib: transparent_stack(lib, 1300),
+    "transparent_stack_clipped": transparent_stack_clipped,
     "ragged": ragged_draws,
     "empty": empty_frame,
 }
