@@ -301,11 +301,13 @@ struct Codec<SVR_COLOR_RGBA8> {
 // is what in-order GREATER_OR_EQUAL with depth write leaves behind, so no order is needed.  The
 // record is implied by the key: key - 1 is the triangle's main slot (a clipped parent's slot links to
 // its pieces, see resolve_record).
-template <bool INSTR>
-__device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov, uint32_t bin_base, uint32_t n,
+// LIST: the record indices come from s_list (LDS: a quarter's row-filtered copy of the bin) instead of the bin.
+template <bool INSTR, bool LIST>
+__device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov, const uint32_t* s_list, uint32_t bin_base, uint32_t n,
                                              unsigned long long* s_depth, int tx0, int ty0, int ry0, int nrows,
                                              uint32_t& n_raster) {
   // rows [ry0, ry0 + nrows) of the tile at (tx0, ty0): the whole tile, or one quarter of a split tile
+  auto entry = [&](uint32_t i) -> uint32_t { return LIST ? s_list[i] : P.bins[bin_base + i]; };
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   // Staging is double-buffered through registers: the next batch's records (two 16-byte pieces per thread,
   // behind the dependent bin -> record load) are in flight while this batch is walked.  Single-buffered,
@@ -314,8 +316,8 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
   uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0;
   {
     uint32_t cnt = min((uint32_t)BATCH, n);
-    if (threadIdx.x < cnt * 8u) pre0 = reinterpret_cast<const uint4*>(P.recs + P.bins[bin_base + (threadIdx.x >> 3)])[threadIdx.x & 7u];
-    if (threadIdx.x + 256u < cnt * 8u) pre1 = reinterpret_cast<const uint4*>(P.recs + P.bins[bin_base + 32u + (threadIdx.x >> 3)])[threadIdx.x & 7u];
+    if (threadIdx.x < cnt * 8u) pre0 = reinterpret_cast<const uint4*>(P.recs + entry(threadIdx.x >> 3))[threadIdx.x & 7u];
+    if (threadIdx.x + 256u < cnt * 8u) pre1 = reinterpret_cast<const uint4*>(P.recs + entry(32u + (threadIdx.x >> 3)))[threadIdx.x & 7u];
   }
   for (uint32_t b0 = 0; b0 < n; b0 += BATCH) {
     uint32_t cnt = min((uint32_t)BATCH, n - b0);
@@ -325,8 +327,8 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
     __syncthreads();
     if (b0 + BATCH < n) {
       uint32_t nb = b0 + BATCH, ncnt = min((uint32_t)BATCH, n - nb);
-      if (threadIdx.x < ncnt * 8u) pre0 = reinterpret_cast<const uint4*>(P.recs + P.bins[bin_base + nb + (threadIdx.x >> 3)])[threadIdx.x & 7u];
-      if (threadIdx.x + 256u < ncnt * 8u) pre1 = reinterpret_cast<const uint4*>(P.recs + P.bins[bin_base + nb + 32u + (threadIdx.x >> 3)])[threadIdx.x & 7u];
+      if (threadIdx.x < ncnt * 8u) pre0 = reinterpret_cast<const uint4*>(P.recs + entry(nb + (threadIdx.x >> 3)))[threadIdx.x & 7u];
+      if (threadIdx.x + 256u < ncnt * 8u) pre1 = reinterpret_cast<const uint4*>(P.recs + entry(nb + 32u + (threadIdx.x >> 3)))[threadIdx.x & 7u];
     }
     // lane i: column count of triangle i inside this tile
     int cx0 = 0, cw = 0;
@@ -433,6 +435,7 @@ __device__ __forceinline__ uint32_t resolve_record(const FrameParams& P, uint32_
 // (the result of a min does not depend on lane execution order).
 constexpr uint32_t SORT_CAP = 2048;                       // bins above this are sorted in the global sort arena instead of LDS
 constexpr uint32_t RANK_SORT_MAX = 2048;                  // bins up to this (all that fit LDS) are sorted by counting ranks, larger ones by the bitonic network
+constexpr uint32_t QUARTER_LIST_CAP = 5120;               // entries of a quarter's row-filtered opaque list (LDS behind the depth tile)
 constexpr uint32_t QUEUE_CAP = 128;                       // < 64 carried over + up to 64 new per row step
 constexpr uint32_t WAVE_C_BYTES = 256 * 8 + QUEUE_CAP * 8 + 256 * 8 + 64 * 16;  // colour band | queue | lane mask per pixel | shaded colours
 constexpr uint32_t PHASE_C_BYTES = 4 * WAVE_C_BYTES + TILE * TILE * 4;  // + the tile's opaque depth bits
@@ -766,7 +769,45 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
     unsigned long long* s_depth = reinterpret_cast<unsigned long long*>(s_c);  // 8 KiB of the phase-C block
     int tx0 = (int)(P.sx + tx * TILE), ty0 = (int)(P.sy + ty * TILE);
     for (uint32_t i = threadIdx.x; i < TILE * TILE; i += 256u) s_depth[i] = 0ull;  // ordered by scan_columns' first barrier
-    scan_columns<INSTR>(P, s_cov, off_op, n_op, s_depth, tx0, ty0, QUARTER ? sub_y0 : ty0, nrows, n_raster);
+    if (QUARTER && n_op > 2u * BATCH && n_op <= QUARTER_LIST_CAP) {
+      // A quarter of an opaque-heavy tile: most of the bin's triangles do not reach its 8 rows, and staging
+      // them costs as much as in the whole tile.  One pass over the record headers (indices, then bounding
+      // rows: two round trips per 1024 entries) leaves the quarter's own list in LDS, behind the depth tile.
+      uint32_t* s_list = reinterpret_cast<uint32_t*>(s_c + TILE * TILE * 8);
+      const uint32_t lane_ = threadIdx.x & 63u;
+      if (threadIdx.x == 0) s_idx[0] = 0u;
+      __syncthreads();
+      for (uint32_t base = 0; base < n_op; base += 1024u) {
+        uint32_t ri[4];
+        uint2 box[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+          uint32_t i = base + 256u * k + threadIdx.x;
+          ri[k] = i < n_op ? P.bins[off_op + i] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+          uint32_t i = base + 256u * k + threadIdx.x;
+          box[k] = i < n_op ? *reinterpret_cast<const uint2*>(P.recs + ri[k]) : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+          uint32_t i = base + 256u * k + threadIdx.x;
+          int miny = (int)(int16_t)(box[k].x >> 16), maxy = (int)(int16_t)(box[k].y >> 16);
+          bool keep = i < n_op && maxy >= sub_y0 && miny <= sub_y0 + nrows - 1;
+          unsigned long long m = __ballot(keep);
+          uint32_t at = 0;
+          if (lane_ == 0 && m) at = atomicAdd(&s_idx[0], (uint32_t)__popcll(m));  // LDS
+          at = __shfl(at, 0);
+          if (keep) s_list[at + (uint32_t)__popcll(m & ((1ull << lane_) - 1ull))] = ri[k];
+        }
+      }
+      __syncthreads();
+      const uint32_t n_mine = s_idx[0];
+      scan_columns<INSTR, true>(P, s_cov, s_list, 0u, n_mine, s_depth, tx0, ty0, sub_y0, nrows, n_raster);
+    } else {
+      scan_columns<INSTR, false>(P, s_cov, nullptr, off_op, n_op, s_depth, tx0, ty0, QUARTER ? sub_y0 : ty0, nrows, n_raster);
+    }
     __syncthreads();
     // (the pixel's place in the tile is recomputed from the thread index behind a compiler barrier: kept live
     // across the scan it was spilled to scratch, and the two reloads stood in front of every tile's phase B)
@@ -956,6 +997,7 @@ __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
   __shared__ uint4 s_cov[BATCH * 8];
   __shared__ uint32_t s_idx[BATCH];
   __shared__ __attribute__((aligned(16))) unsigned char s_c[PHASE_C_BYTES];  // phase A depth tile, phase C blocks
+  static_assert(TILE * TILE * 8 + QUARTER_LIST_CAP * 4 <= PHASE_C_BYTES, "depth tile + a quarter's triangle list");
   static_assert(SPLIT_SORT_MAX <= SORT_CAP && PHASE_C_BYTES >= SORT_CAP * 8 && PHASE_C_BYTES >= TILE * TILE * 8, "sort scratch and depth tile alias the block");
 
   // Everything the workgroup needs before it can start comes in ONE round of scalar loads: the failure flags
