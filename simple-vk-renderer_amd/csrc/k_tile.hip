@@ -22,6 +22,7 @@
 //            time, blended at target precision; bins over 2048 entries sort in a global arena instead
 //   phase D  write-back: whole tiles go out through LDS as full rows, the depth CLEAR and a deferred
 //            svr_clear_color are fused here
+// Heavy tiles of small passes are rendered as four 8-row quarters by four workgroups (tile_kernel<.., SPLIT>).
 // What bounds it is VALU issue (the fragment stage is ~400-460 instructions per pixel), not HBM:
 // DESIGN.md "Tile kernel".  128 VGPRs = 4 workgroups per CU.
 #include <hip/hip_fp16.h>
@@ -424,15 +425,15 @@ __device__ __forceinline__ uint32_t resolve_record(const FrameParams& P, uint32_
 // ------------------------------------------------------------------------------------------------
 // Transparent pass, ordered form.  Blending is order dependent (the target rounds after every
 // blend), so fragments must reach each pixel in submission order.  The tile's transparent bin is
-// sorted by submission key once (bitonic sort in LDS, written back in place), then scanned once with
-// the same (triangle, column) items as phase A.  For the order to survive, wave w owns the tile's
+// sorted by submission key once (rank_sort below), then scanned once with the same (triangle, column)
+// items as phase A.  For the order to survive, wave w owns the tile's
 // rows 8w..8w+7: it takes the items of every triangle that touches its band, in bin order, and all
 // its lanes step through the SAME absolute row at the same time — so the fragments of one pixel are
 // appended to the wave's LDS queue in submission order (__ballot + prefix popcount: lane order is
 // item order).  Depth-passing fragments are shaded 64 at a time by whichever lanes are free and
 // blended into the wave's LDS colour band.  Several fragments of one pixel can sit in the same group
-// of 64: they are applied in queue order by electing, per pixel, the lowest pending lane with ds_min
-// (the result of a min does not depend on lane execution order).
+// of 64: the lowest lane of every pixel applies them in lane order = queue order (flush_fragments).
+// In a quarter of a split tile (svr_device.h SPLIT_*) a wave owns 2 rows instead of 8.
 constexpr uint32_t SORT_CAP = 2048;                       // bins above this are sorted in the global sort arena instead of LDS
 constexpr uint32_t RANK_SORT_MAX = 2048;                  // bins up to this (all that fit LDS) are sorted by counting ranks, larger ones by the bitonic network
 constexpr uint32_t QUARTER_LIST_CAP = 5120;               // entries of a quarter's row-filtered opaque list (LDS behind the depth tile)
