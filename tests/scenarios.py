@@ -342,6 +342,8 @@ SCENARIOS = {
     "transparent_stack_1000": lambda lib: transparent_stack(lib, 1000, jitter=0.01, seed=8),
     # ~1000 opaque triangles per tile: split by the opaque term of the cost alone
     "soup_dense_split": lambda lib: random_soup(lib, w=96, h=64, seed=13, n_tris=6000, transparent_every=7),
+    # ~9000 opaque triangles per tile: more than a quarter's row-filtered list holds in LDS (it walks the bin itself)
+    "soup_very_dense_split": lambda lib: random_soup(lib, w=64, h=64, seed=17, n_tris=36000, transparent_every=9),
     "transparent_stack_1300_fallback": lambda lib: transparent_stack(lib, 1300),
     "transparent_stack_clipped": transparent_stack_clipped,
     "ragged": ragged_draws,
