@@ -144,7 +144,12 @@ __device__ __forceinline__ uint32_t weight_class(const FrameParams& P, uint32_t 
 
 __global__ __launch_bounds__(256) void offsets_kernel(FrameParams P) {
   __shared__ uint32_t l_cnt[33];
-  if (P.counters->overflow) return;
+  __shared__ uint32_t s_void;
+  // Other blocks of this kernel raise the flag while it runs: the early exit must be one decision per
+  // block (barriers follow), so one thread reads it and the block takes its word.
+  if (threadIdx.x == 0) s_void = P.counters->overflow;
+  __syncthreads();
+  if (s_void) return;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t n = 2u * P.n_tiles;
   if (threadIdx.x < 33) l_cnt[threadIdx.x] = 0;
@@ -177,7 +182,10 @@ __global__ __launch_bounds__(256) void offsets_kernel(FrameParams P) {
 // A block ranks its tiles per class in LDS and takes one span per class from the global cursors.
 __global__ __launch_bounds__(256) void fill_kernel(FrameParams P) {
   __shared__ uint32_t l_cnt[33], l_base[33];
-  if (P.counters->overflow) return;
+  __shared__ uint32_t s_void;
+  if (threadIdx.x == 0) s_void = P.counters->overflow;  // raised concurrently by other blocks: one decision per block
+  __syncthreads();
+  if (s_void) return;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (blockIdx.x * blockDim.x < P.n_tiles) {  // block-uniform
     if (threadIdx.x < 33) l_cnt[threadIdx.x] = 0;

@@ -32,7 +32,11 @@ __global__ __launch_bounds__(256, 4) void setup_kernel(FrameParams P) {
   // device-flattened passes: the grid was sized by the host's upper bound, the real count is on the device
   const uint32_t n_chunks = P.flatten ? P.counters->flat_chunks : P.n_chunks;
   const bool live = gw < n_chunks;  // wave-uniform; dead waves only attend the barriers
-  WaveChunk ch = P.chunks[live ? gw : 0u];
+  // a dead wave touches neither the chunk list nor a draw it names: with every object culled the device
+  // flatten writes no chunk at all and chunks[0] holds whatever an earlier pass left there (draws[0] is
+  // always inside the inputs allocation; nothing read from it is used by a dead wave)
+  WaveChunk ch{0u, 0u};
+  if (live) ch = P.chunks[gw];
   const DrawDesc& d = P.draws[ch.draw];
   uint32_t tri = live ? ch.first_tri + lane : 0xffffffffu;
   uint32_t seq = d.tri_base + tri;

@@ -1021,9 +1021,16 @@ __global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
   // A pass that overflowed a queue is void, and so is everything after it until the host has replayed
   // it (svr_api.hip "the operation log"): the targets stay as they were before the failed pass.
   if (overflow | poison) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && poison == 0u) {  // the first failure: flag + tell the host which pass
-      *P.poison = 1u;
-      __hip_atomic_store(P.host_failed_seq, P.op_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (blockIdx.x == 0 && poison == 0u) {  // the first failure: flag + tell the host which pass, and by how much
+      // its counters go along (they keep counting past the capacities), so the replay can size the queues
+      // before its first attempt; the set's device copy may be zeroed by a later pass's prologue by then
+      if (threadIdx.x < sizeof(Counters) / 4)
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(P.host_counters) + threadIdx.x,
+                           reinterpret_cast<const uint32_t*>(P.counters)[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (threadIdx.x == 0) {
+        *P.poison = 1u;
+        __hip_atomic_store(P.host_failed_seq, P.op_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   } else if (SPLIT) {
     if (blockIdx.x < SPLIT_EXTRA) {  // the quarters of split tiles, as many as fill_kernel made

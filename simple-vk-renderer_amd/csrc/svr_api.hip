@@ -503,6 +503,7 @@ int submit_clear(SvrContext* ctx, const SvrContext::LoggedOp& op) {  // every lo
 int recover_from_overflow(SvrContext* ctx) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->gstream));
+  const uint32_t failed_seq = *(volatile uint32_t*)ctx->h_failed_seq;
   *ctx->h_failed_seq = 0;
   for (SvrContext::LoggedOp& op : ctx->log) {
     if (!op.is_pass) {
@@ -513,6 +514,9 @@ int recover_from_overflow(SvrContext* ctx) {
     bool done = false;
     Counters c;
     std::memset(&c, 0, sizeof(c));
+    // the pass that failed reported its counters with its number (tile_kernel): grow before the first replay.
+    // The passes behind it were only void, not known to overflow: they start from the capacities as they are.
+    if (op.seq == failed_seq && ctx->h_counters[op.slot].overflow) c = ctx->h_counters[op.slot];
     for (int attempt = 0; attempt < 13 && !done; attempt++) {
       if (c.overflow & 1u) ctx->clip_cap = std::max<uint32_t>(ctx->clip_cap * 2u, c.n_clip + 1024u);
       if (c.overflow & 2u) ctx->extra_cap = std::max<uint32_t>(ctx->extra_cap * 2u, c.n_extra + 1024u);
@@ -690,9 +694,13 @@ int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& 
     n_chunks += (d.tri_count + 63u) / 64u;
   }
   FrameParams P;
+  const SvrContext::PendingClear asked = ctx->pending_clear;  // folded into P.lazy_clear below: put back if the pass is not enqueued
   if (int e = fill_frame_params(ctx, scene, n_tris64, n_chunks, P)) return e;
   int slot = 0;
-  if (int e = log_slot(ctx, &slot)) return e;
+  if (int e = log_slot(ctx, &slot)) {
+    if (P.lazy_clear) ctx->pending_clear = asked;
+    return e;
+  }
   ctx->log.emplace_back();
   SvrContext::LoggedOp& op = ctx->log.back();
   op.is_pass = true;
@@ -705,6 +713,7 @@ int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& 
   std::memset(&ctx->h_counters[slot], 0, sizeof(Counters));
   if (int e = submit_pass(ctx, op.P, op.draws, slot, op.seq, !(ctx->tuning & TUNE_NO_PIPELINE))) {
     ctx->log.pop_back();
+    if (P.lazy_clear) ctx->pending_clear = asked;
     return e;
   }
   return SVR_OK;
@@ -741,10 +750,14 @@ int run_pass_flatten(SvrContext* ctx, const SvrSceneData* scene, const SvrRender
   if (int e = poll_pending(ctx)) return e;
   if (int e = upload_flatten_tables(ctx)) return e;
   FrameParams P;
+  const SvrContext::PendingClear asked = ctx->pending_clear;
   if (int e = fill_frame_params(ctx, scene, tris_max, chunks_max, P)) return e;
   P.flatten = 1u;
   int slot = 0;
-  if (int e = log_slot(ctx, &slot)) return e;
+  if (int e = log_slot(ctx, &slot)) {
+    if (P.lazy_clear) ctx->pending_clear = asked;
+    return e;
+  }
   ctx->log.emplace_back();
   SvrContext::LoggedOp& op = ctx->log.back();
   op.is_pass = true;
@@ -761,6 +774,7 @@ int run_pass_flatten(SvrContext* ctx, const SvrSceneData* scene, const SvrRender
   std::memset(&ctx->h_counters[slot], 0, sizeof(Counters));
   if (int e = submit_pass(ctx, op.P, op.draws, slot, op.seq, !(ctx->tuning & TUNE_NO_PIPELINE), &op)) {
     ctx->log.pop_back();
+    if (P.lazy_clear) ctx->pending_clear = asked;
     return e;
   }
   return SVR_OK;

