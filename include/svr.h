@@ -291,6 +291,15 @@ int svr_debug_read_bins(SvrContext* ctx, uint32_t* counts, size_t capacity, uint
  * HIP library only. */
 int svr_debug_read_tile_cycles(SvrContext* ctx, uint32_t* cycles, size_t capacity);
 
+/* Test hook for the arithmetic contract's "IEEE 1/x" (perspective divide, 1/area, 1/q per fragment): compares the
+ * reciprocal exactly as the kernels compute it with the compiler's correctly rounded 1.0f / x for the fp32 bit
+ * patterns first .. first + count - 1 (all 2^32 in one call is a few milliseconds).  variant 0 = the production
+ * form, 1 / 2 = its candidate refinements without the fallback.  *mismatches = inputs whose result bits differ
+ * (NaN == NaN), *refined = inputs that took the refined (division-free) path, first_bad = up to 16 of the
+ * mismatching patterns; the last two may be NULL.  HIP library only. */
+int svr_debug_rcp_sweep(SvrContext* ctx, int variant, uint64_t first, uint64_t count, uint64_t* mismatches,
+                        uint64_t* refined, uint32_t first_bad[16]);
+
 /* fence wait (vkWaitForFences, src/vk_engine.cpp:1226) */
 int svr_sync(SvrContext* ctx);
 

@@ -1249,6 +1249,10 @@ int svr_debug_read_bins(SvrContext*, uint32_t*, size_t, uint32_t*) {
   return fail(SVR_ERR_UNSUPPORTED, "svr_debug_read_bins: the CPU oracle does not bin");
 }
 
+int svr_debug_rcp_sweep(SvrContext*, int, uint64_t, uint64_t, uint64_t*, uint64_t*, uint32_t*) {
+  return fail(SVR_ERR_UNSUPPORTED, "svr_debug_rcp_sweep: the CPU oracle divides (1.0f / x) everywhere");
+}
+
 int svr_debug_read_tile_cycles(SvrContext*, uint32_t*, size_t) {
   return fail(SVR_ERR_UNSUPPORTED, "svr_debug_read_tile_cycles: the CPU oracle has no tiles");
 }

@@ -82,7 +82,7 @@ SYMBOLS = ["svr_create", "svr_destroy", "svr_set_stream", "svr_bind_targets", "s
            "svr_read_image_level", "svr_create_sampler", "svr_write_material", "svr_clear_color",
            "svr_draw_background", "svr_copy_to_swapchain", "svr_read_swapchain",
            "svr_set_scissor", "svr_draw_geometry", "svr_draw_colored_triangle", "svr_draw_tex_image",
-           "svr_run_mesh_vert", "svr_set_option", "svr_debug_trace_pixel", "svr_debug_read_trace", "svr_debug_read_bins", "svr_debug_read_tile_cycles", "svr_sync", "svr_read_color", "svr_read_depth", "svr_get_stats",
+           "svr_run_mesh_vert", "svr_set_option", "svr_debug_trace_pixel", "svr_debug_read_trace", "svr_debug_read_bins", "svr_debug_read_tile_cycles", "svr_debug_rcp_sweep", "svr_sync", "svr_read_color", "svr_read_depth", "svr_get_stats",
            "svr_last_error", "svr_backend_name"]
 
 
@@ -136,6 +136,8 @@ class SvrLib:
         L.svr_debug_read_trace.argtypes = [P, P]
         L.svr_debug_read_bins.argtypes = [P, P, C.c_size_t, C.POINTER(C.c_uint32)]
         L.svr_debug_read_tile_cycles.argtypes = [P, P, C.c_size_t]
+        if hasattr(L, "svr_debug_rcp_sweep"):  # tools/ab_libs.py also loads builds that predate it
+            L.svr_debug_rcp_sweep.argtypes = [P, C.c_int, C.c_uint64, C.c_uint64, P, P, P]
         L.svr_sync.argtypes = [P]
         L.svr_read_color.argtypes = [P, P, C.c_size_t, C.c_int]
         L.svr_read_depth.argtypes = [P, P, C.c_size_t]
@@ -317,6 +319,13 @@ class Renderer:
         out = np.zeros((n.value, 4), dtype=np.uint32)
         self.lib.check(self.lib.lib.svr_debug_read_tile_cycles(self.h, out.ctypes.data, out.size))
         return out
+
+    def rcp_sweep(self, variant=0, first=0, count=1 << 32):
+        """(mismatches, inputs on the refined path, first mismatching bit patterns) of svr_debug_rcp_sweep."""
+        bad, fast = C.c_uint64(), C.c_uint64()
+        pats = np.zeros(16, dtype=np.uint32)
+        self.lib.check(self.lib.lib.svr_debug_rcp_sweep(self.h, variant, first, count, C.byref(bad), C.byref(fast), pats.ctypes.data))
+        return bad.value, fast.value, pats[:min(bad.value, 16)]
 
     def read_trace(self):
         out = np.zeros(64, dtype=np.float32)

@@ -230,6 +230,48 @@ void launch_blit(const void* color, int color_format, uint32_t W, uint32_t H, vo
                      row_first, n_rows, dst_format, poison);
 }
 
+// Test hook: the contract's "IEEE 1/x" as the kernels compute it (rcp_ieee / its candidate refinements)
+// against the compiler's correctly rounded division, over a range of fp32 bit patterns.  out[0] = mismatches,
+// out[1] = inputs that took the refined path, out[2..17] = the first mismatching patterns.
+template <int VARIANT>
+__global__ __launch_bounds__(256) void rcp_sweep_kernel(unsigned long long first, unsigned long long count, unsigned long long* out) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  unsigned long long bad = 0, fast = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    const uint32_t bits = (uint32_t)(first + i);
+    const float x = u2f(bits);
+    float want = 1.0f / x, got;
+    if (VARIANT == 0) {
+      got = rcp_ieee(x);
+      fast += rcp_fast_ok(x) ? 1u : 0u;
+    } else {
+      got = rcp_fast_ok(x) ? rcp_refined<VARIANT>(x) : want;
+      fast += rcp_fast_ok(x) ? 1u : 0u;
+    }
+    const bool same = f2u(want) == f2u(got) || (want != want && got != got);
+    if (!same) {
+      unsigned long long k = bad++;
+      (void)k;
+      unsigned long long slot = atomicAdd(&out[18], 1ull);
+      if (slot < 16) out[2 + slot] = bits;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    bad += __shfl_down(bad, off);
+    fast += __shfl_down(fast, off);
+  }
+  if ((threadIdx.x & 63u) == 0) {
+    if (bad) atomicAdd(&out[0], bad);
+    atomicAdd(&out[1], fast);
+  }
+}
+void launch_rcp_sweep(int variant, unsigned long long first, unsigned long long count, unsigned long long* out, hipStream_t s) {
+  dim3 grid(4096), block(256);
+  if (variant == 1) hipLaunchKernelGGL(rcp_sweep_kernel<1>, grid, block, 0, s, first, count, out);
+  else if (variant == 2) hipLaunchKernelGGL(rcp_sweep_kernel<2>, grid, block, 0, s, first, count, out);
+  else hipLaunchKernelGGL(rcp_sweep_kernel<0>, grid, block, 0, s, first, count, out);
+}
+
 void launch_rgba16f_to_rgba8(const void* src, void* dst, uint32_t n_pixels, hipStream_t s) {
   hipLaunchKernelGGL(cvt16f_to_8_kernel, dim3(stream_grid(n_pixels)), dim3(256), 0, s, (const uint2*)src,
                      (uint32_t*)dst, n_pixels);

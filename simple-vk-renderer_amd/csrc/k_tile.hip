@@ -29,6 +29,8 @@
 
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "svr_launch.h"
 
 namespace svr {
@@ -57,22 +59,21 @@ __device__ __forceinline__ float lod_from_rho2(float rho2) {
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return fmaf(t, b - a, a); }
 
 struct TexD {
-  const uint8_t* base;
+  uint32_t base_off;  // level 0 in the texel arena
   uint32_t w, h, lw, lh, levels, filters;
   float min_lod, max_lod;
 };
 
-// the four texel byte offsets and the two weights of one mip level; NEAREST is the same footprint
-// with both taps on floor(U) and weight 0 (lerp(t,t,0) == t exactly), so the path is branch-free
+// the four texel byte offsets (from the texel arena's base) and the two weights of one mip level; NEAREST is
+// the same footprint with both taps on floor(U) and weight 0 (lerp(t,t,0) == t exactly), so the path is branch-free
 struct Taps {
   uint32_t o00, o10, o01, o11;
   float alpha, beta;
 };
+// wl, hl: the level's extent; base: its byte offset in the arena.
 // POW2: the image's extents are powers of two (part of the COMMON case): REPEAT is a mask
 template <bool POW2 = false>
-__device__ __forceinline__ Taps level_taps(const TexD& t, uint32_t level, bool linear, float u, float v) {
-  int wl = (int)max(t.w >> level, 1u), hl = (int)max(t.h >> level, 1u);
-  uint32_t base = mip_offset(t.lw, t.lh, level);
+__device__ __forceinline__ Taps level_taps(int wl, int hl, uint32_t base, bool linear, float u, float v) {
   float U = (u - floorf(u)) * (float)wl;
   float V = (v - floorf(v)) * (float)hl;
   float Uh = U - 0.5f, Vh = V - 0.5f;
@@ -102,6 +103,11 @@ __device__ __forceinline__ Taps level_taps(const TexD& t, uint32_t level, bool l
   tp.o01 = base + (r1 + (uint32_t)i0) * 4u;
   tp.o11 = base + (r1 + (uint32_t)i1) * 4u;
   return tp;
+}
+// a texel: the arena's base is wave-uniform (a kernel argument), the offset 32 bits per lane — a global load
+// with an SGPR base, no 64-bit address arithmetic
+__device__ __forceinline__ uint32_t texel(const uint8_t* arena, uint32_t off) {
+  return *reinterpret_cast<const uint32_t*>(arena + off);
 }
 __device__ __forceinline__ float chan(uint32_t t, int c) { return (float)((t >> (8 * c)) & 0xffu) * kInv255; }
 __device__ __forceinline__ float bilerp(uint32_t t00, uint32_t t10, uint32_t t01, uint32_t t11, int c, float a, float b) {
@@ -144,7 +150,7 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
   e1 = fma(A1, dx, fma(B1, dy, C1)) + ((flags & F_T1) ? 1.0 : 0.0);
   e2 = fma(A2, dx, fma(B2, dy, C2)) + ((flags & F_T2) ? 1.0 : 0.0);
   TexD t;
-  t.base = reinterpret_cast<const uint8_t*>(__double_as_longlong(c6.y));
+  t.base_off = (uint32_t)(unsigned long long)__double_as_longlong(c6.y);
   t.w = td.x & 0xffffu;
   t.h = td.x >> 16;
   t.lw = td.y & 0xffu;
@@ -156,18 +162,26 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
   // e1,e2: unbiased edge values at the pixel; its horizontal / vertical quad partners are +-A, +-B away
   float b1 = (float)e1 * inv_area, b2 = (float)e2 * inv_area;
   float q0 = s0.x, dq1 = s0.y, dq2 = s0.z;
-  float r = 1.0f / fmaf(b2, dq2, fmaf(b1, dq1, q0));
+  double sxp = (px & 1) ? -1.0 : 1.0, syp = (py & 1) ? -1.0 : 1.0;
+  float hb1 = (float)fma(sxp, A1, e1) * inv_area, hb2 = (float)fma(sxp, A2, e2) * inv_area;
+  float vb1 = (float)fma(syp, B1, e1) * inv_area, vb2 = (float)fma(syp, B2, e2) * inv_area;
+  const float qq = fmaf(b2, dq2, fmaf(b1, dq1, q0)), hq = fmaf(hb2, dq2, fmaf(hb1, dq1, q0)), vq = fmaf(vb2, dq2, fmaf(vb1, dq1, q0));
+  float r, hr, vr;
+  if (COMMON) {
+    rcp3_ieee(qq, hq, vq, r, hr, vr);  // one exponent-window test for the three
+  } else {
+    r = rcp_ieee(qq);
+  }
   const uint32_t kind = COMMON ? (uint32_t)PIPE_MESH : ((flags >> F_KIND_SHIFT) & 3u);
   float cr = interp3(s1.z, s3.z, s5.z, b1, b2, r);
   float cg = interp3(s1.w, s3.w, s5.w, b1, b2, r);
   float cb = interp3(s2.x, s4.x, s6.x, b1, b2, r);
   if (kind == PIPE_COLORED_TRIANGLE) return make_float4(cr, cg, cb, 1.0f);  // shaders/colored_triangle.frag:9-12
   float u = interp3(s2.y, s4.y, s6.y, b1, b2, r), v = interp3(s2.z, s4.z, s6.z, b1, b2, r);
-  double sxp = (px & 1) ? -1.0 : 1.0, syp = (py & 1) ? -1.0 : 1.0;
-  float hb1 = (float)fma(sxp, A1, e1) * inv_area, hb2 = (float)fma(sxp, A2, e2) * inv_area;
-  float vb1 = (float)fma(syp, B1, e1) * inv_area, vb2 = (float)fma(syp, B2, e2) * inv_area;
-  float hr = 1.0f / fmaf(hb2, dq2, fmaf(hb1, dq1, q0));
-  float vr = 1.0f / fmaf(vb2, dq2, fmaf(vb1, dq1, q0));
+  if (!COMMON) {
+    hr = rcp_ieee(hq);
+    vr = rcp_ieee(vq);
+  }
   float uh = interp3(s2.y, s4.y, s6.y, hb1, hb2, hr), vh = interp3(s2.z, s4.z, s6.z, hb1, hb2, hr);
   float uv_ = interp3(s2.y, s4.y, s6.y, vb1, vb2, vr), vv_ = interp3(s2.z, s4.z, s6.z, vb1, vb2, vr);
   float dudx = (px & 1) ? (u - uh) : (uh - u);
@@ -190,10 +204,13 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
   float delta = mip_linear ? lc - fl : 0.0f;
   int dlo = mip_linear ? min(dhi + 1, q) : dn;
   float us = (fabsf(u) < 8388608.0f) ? u : 0.0f, vs = (fabsf(v) < 8388608.0f) ? v : 0.0f;
-  Taps th = level_taps<COMMON>(t, (uint32_t)dhi, linear, us, vs);
-  const uint8_t* tb = t.base;
-  uint32_t h00 = *reinterpret_cast<const uint32_t*>(tb + th.o00), h10 = *reinterpret_cast<const uint32_t*>(tb + th.o10);
-  uint32_t h01 = *reinterpret_cast<const uint32_t*>(tb + th.o01), h11 = *reinterpret_cast<const uint32_t*>(tb + th.o11);
+  // level extents and arena offsets.  The layout pads every level to powers of two (svr_device.h mip_offset), so
+  // the next level starts one padded level further on: no second evaluation of the closed form.
+  const int whi = (int)max(t.w >> dhi, 1u), hhi = (int)max(t.h >> dhi, 1u);
+  const uint32_t bhi = t.base_off + mip_offset(t.lw, t.lh, (uint32_t)dhi);
+  Taps th = level_taps<COMMON>(whi, hhi, bhi, linear, us, vs);
+  const uint8_t* tb = P.tex_arena;
+  uint32_t h00 = texel(tb, th.o00), h10 = texel(tb, th.o10), h01 = texel(tb, th.o01), h11 = texel(tb, th.o11);
   // The second level only matters where delta != 0 (lerp(H, L, 0) == H exactly): magnified and
   // NEAREST-mip pixels skip its four taps when no lane of the wave needs them.  Its loads are issued
   // before anything consumes the first level's texels, so both batches are in flight together.
@@ -201,11 +218,14 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
   Taps tl = th;
   uint32_t l00 = 0, l10 = 0, l01 = 0, l11 = 0;
   if (two_levels) {
-    tl = level_taps<COMMON>(t, (uint32_t)dlo, linear, us, vs);
-    l00 = *reinterpret_cast<const uint32_t*>(tb + tl.o00);
-    l10 = *reinterpret_cast<const uint32_t*>(tb + tl.o10);
-    l01 = *reinterpret_cast<const uint32_t*>(tb + tl.o01);
-    l11 = *reinterpret_cast<const uint32_t*>(tb + tl.o11);
+    const int wlo = (int)max(t.w >> dlo, 1u), hlo = (int)max(t.h >> dlo, 1u);
+    const uint32_t step = 4u << ((uint32_t)max((int)t.lw - dhi, 0) + (uint32_t)max((int)t.lh - dhi, 0));  // padded bytes of level dhi
+    const uint32_t blo = dlo != dhi ? bhi + step : bhi;
+    tl = level_taps<COMMON>(wlo, hlo, blo, linear, us, vs);
+    l00 = texel(tb, tl.o00);
+    l10 = texel(tb, tl.o10);
+    l01 = texel(tb, tl.o01);
+    l11 = texel(tb, tl.o11);
   }
   float4 tx;
   tx.x = bilerp(h00, h10, h01, h11, 0, th.alpha, th.beta);
@@ -435,11 +455,9 @@ __device__ __forceinline__ uint32_t resolve_record(const FrameParams& P, uint32_
 // of 64: the lowest lane of every pixel applies them in lane order = queue order (flush_fragments).
 // In a quarter of a split tile (svr_device.h SPLIT_*) a wave owns 2 rows instead of 8.
 constexpr uint32_t SORT_CAP = 2048;                       // bins above this are sorted in the global sort arena instead of LDS
-constexpr uint32_t RANK_SORT_MAX = 2048;                  // bins up to this (all that fit LDS) are sorted by counting ranks, larger ones by the bitonic network
+constexpr uint32_t RANK_SORT_MAX = 1024;                  // bins up to this are ranked on their 32-bit keys (rank_sort), up to SORT_CAP by rank_sort_big
 constexpr uint32_t QUARTER_LIST_CAP = 5120;               // entries of a quarter's row-filtered opaque list (LDS behind the depth tile)
 constexpr uint32_t QUEUE_CAP = 128;                       // < 64 carried over + up to 64 new per row step
-constexpr uint32_t WAVE_C_BYTES = 256 * 8 + QUEUE_CAP * 8 + 256 * 8 + 64 * 16;  // colour band | queue | lane mask per pixel | shaded colours
-constexpr uint32_t PHASE_C_BYTES = 4 * WAVE_C_BYTES + TILE * TILE * 4;  // + the tile's opaque depth bits
 
 template <int FMT, bool INSTR>
 __device__ __forceinline__ void flush_fragments(const FrameParams& P, typename Codec<FMT>::enc_t* col, uint2* q,
@@ -563,17 +581,22 @@ __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4
       const double2* d = reinterpret_cast<const double2*>(rec);
       double2 c2 = d[2], c3 = d[3], c4 = d[4], c5 = d[5], c6 = d[6];
       double B0 = c3.y, B1 = c4.x, B2 = c4.y;
-      double u1 = (flags & F_T1) ? 1.0 : 0.0, u2 = (flags & F_T2) ? 1.0 : 0.0;
       double dx = (double)(tx0 + colx), dy = (double)by0;
       double f0 = fma(c2.x, dx, fma(B0, dy, c5.x));
-      double f1 = fma(c2.y, dx, fma(B1, dy, c5.y));
-      double f2 = fma(c3.x, dx, fma(B2, dy, c6.x));
+      // edges 1 and 2 are walked UNBIASED (g = f + 1 where C carries the top-left bias, else f): that is the value the
+      // barycentrics want, and for integers "f >= 0" is "g > 0" there and "g >= 0" elsewhere — two compares where
+      // holding the two 1.0 / 0.0 in registers across walk and flush cost four VGPRs and an add per row
+      // (walking edges 1 and 2 unbiased, with "g > 0" / "g >= 0" picked per lane, saves the two adds and four
+      // registers below but pays more in the compares' mask logic: +4 % on the curtain tiles)
+      const double u1 = (flags & F_T1) ? 1.0 : 0.0, u2 = (flags & F_T2) ? 1.0 : 0.0;
+      double g1 = fma(c2.y, dx, fma(B1, dy, c5.y));
+      double g2 = fma(c3.x, dx, fma(B2, dy, c6.x));
 #pragma unroll 1
       for (int t = 0; t < rpw; t++) {  // the same absolute row by0 + t in every lane
         int y = by0 + t;
-        bool inside = act && y >= y0 && y <= y1 && f0 >= 0.0 && f1 >= 0.0 && f2 >= 0.0;
+        bool inside = act && y >= y0 && y <= y1 && f0 >= 0.0 && g1 >= 0.0 && g2 >= 0.0;
         if (INSTR) n_raster += inside ? 1u : 0u;
-        float b1 = (float)(f1 + u1) * zr.w, b2 = (float)(f2 + u2) * zr.w;
+        float b1 = (float)(g1 + u1) * zr.w, b2 = (float)(g2 + u2) * zr.w;
         float z = fmaf(b2, zr.z, fmaf(b1, zr.y, zr.x));
         z = fminf(fmaxf(z, 0.0f), 1.0f) + 0.0f;
         bool pass = inside && f2u(z) >= s_z[(y - ty0) * TILE + colx];  // GREATER_OR_EQUAL vs opaque depth, no write
@@ -584,8 +607,8 @@ __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4
           if (qn >= 64u) flush_fragments<FMT, INSTR>(P, col, q, mask, s_src, qn, tx0, by0, lane, n_shaded);
         }
         f0 += B0;
-        f1 += B1;
-        f2 += B2;
+        g1 += B1;
+        g2 += B2;
       }
     }
   }
@@ -615,7 +638,7 @@ __device__ __forceinline__ void count_ranks(const KeyT* s, uint32_t n, const Key
 template <uint32_t K>
 __device__ __forceinline__ void rank_sort(const FrameParams& P, unsigned char* lds, uint32_t bin_base, uint32_t n, uint32_t* out) {
   uint32_t* k32 = reinterpret_cast<uint32_t*>(lds);         // [n] keys
-  uint32_t* claim = k32 + RANK_SORT_MAX;                     // [n] element that owns each rank
+  uint32_t* claim = k32 + SORT_CAP;                          // [n] element that owns each rank
   uint32_t ri[K], key[K], rank[K];
 #pragma unroll
   for (uint32_t k = 0; k < K; k++) {
@@ -659,13 +682,89 @@ __device__ __forceinline__ void rank_sort(const FrameParams& P, unsigned char* l
     if (threadIdx.x + 256u * k < n) out[rank[k]] = ri[k];
 }
 
+template <uint32_t K>
+__device__ __forceinline__ void rank_pass(const uint32_t* k32, const uint32_t* r32, uint32_t* marks, uint32_t base, uint32_t n, uint32_t* out) {
+  uint32_t mine[K], rank[K];
+#pragma unroll
+  for (uint32_t k = 0; k < K; k++) {
+    uint32_t i = base + threadIdx.x + 256u * k;
+    mine[k] = i < n ? k32[i] : 0xffffffffu;
+  }
+  count_ranks<K, uint32_t>(k32, n, mine, rank);
+#pragma unroll
+  for (uint32_t k = 0; k < K; k++) {
+    uint32_t i = base + threadIdx.x + 256u * k;
+    if (i < n) {
+      out[rank[k]] = r32[i];
+      marks[rank[k]] = 1u;
+    }
+  }
+}
+
+// Bins of 1025 .. 2048 entries: the same rank by counting with keys AND record indices parked in LDS, every thread
+// taking its eight elements four at a time (eight keys, records and ranks per thread at once were the register
+// peak of the whole kernel, paid for by spills in the phases every tile runs).  Ties (the clipper's pieces of one
+// triangle sharing the tile) leave a rank unclaimed; such a bin is ranked again on (key, position in the bin) —
+// pieces of one triangle never cover the same pixel, so their mutual order is free, and every workgroup that
+// sorts this bin (the quarters of a split tile) reads it in the same order.
+// marks: [SORT_CAP] words of LDS outside the scratch block (the record staging buffer, idle during the sort).
+__device__ __forceinline__ void rank_sort_big(const FrameParams& P, unsigned char* lds, uint32_t* marks, uint32_t bin_base, uint32_t n,
+                                              uint32_t* out) {
+  uint32_t* k32 = reinterpret_cast<uint32_t*>(lds);  // [n] keys
+  uint32_t* r32 = k32 + SORT_CAP;                     // [n] record indices
+  {  // all record indices, then all keys: two round trips for the whole bin
+    uint32_t ri[8], key[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      uint32_t i = threadIdx.x + 256u * k;
+      ri[k] = i < n ? P.bins[bin_base + i] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      uint32_t i = threadIdx.x + 256u * k;
+      key[k] = i < n ? P.recs[ri[k]].key : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      uint32_t i = threadIdx.x + 256u * k;
+      if (i < n) {
+        k32[i] = key[k];
+        r32[i] = ri[k];
+        marks[i] = 0u;
+      }
+    }
+  }
+  __syncthreads();  // every entry of the bin has been read: sorting in place is safe
+  rank_pass<4>(k32, r32, marks, 0u, n, out);
+  switch ((n - 1024u + 255u) >> 8) {  // the elements from 1024 on: as many per thread as there are
+    case 1: rank_pass<1>(k32, r32, marks, 1024u, n, out); break;
+    case 2: rank_pass<2>(k32, r32, marks, 1024u, n, out); break;
+    case 3: rank_pass<3>(k32, r32, marks, 1024u, n, out); break;
+    default: rank_pass<4>(k32, r32, marks, 1024u, n, out); break;
+  }
+  __syncthreads();
+  bool hole = false;
+  for (uint32_t r = threadIdx.x; r < n; r += 256u) hole = hole || marks[r] == 0u;
+  if (__syncthreads_or(hole)) {  // equal keys: rank (key, position)
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+      const uint32_t m = k32[i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < n; j++) {
+        uint32_t v = k32[j];
+        rank += (v < m || (v == m && j < i)) ? 1u : 0u;
+      }
+      out[rank] = r32[i];
+    }
+  }
+}
+
 // s: scratch — the LDS block (>= 16 KiB) for bins up to SORT_CAP, else the tile's span of the global sort arena,
 // the next power of two >= n words (fill_kernel reserved it; global memory is coherent inside a workgroup's CU).
 // out: where the sorted record indices go — the bin itself, or (quarters of a split tile, n <= RANK_SORT_MAX) the
 // tile's words of the sort arena, which all four quarters fill with the same values.
-__device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned long long* s, uint32_t bin_base, uint32_t n,
+__device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned long long* s, uint32_t* marks, uint32_t bin_base, uint32_t n,
                                                 uint32_t* out) {
-  if (n <= RANK_SORT_MAX) {
+  if (n <= SORT_CAP) {
     unsigned char* lds = reinterpret_cast<unsigned char*>(s);
     switch ((n + 255u) >> 8) {
       case 0:
@@ -673,10 +772,14 @@ __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned l
       case 2: rank_sort<2>(P, lds, bin_base, n, out); break;
       case 3: rank_sort<3>(P, lds, bin_base, n, out); break;
       case 4: rank_sort<4>(P, lds, bin_base, n, out); break;
+#ifdef SVR_AB_RANK8  // A/B builds only: eight elements per thread in registers (the register peak of the kernel)
       case 5: rank_sort<5>(P, lds, bin_base, n, out); break;
       case 6: rank_sort<6>(P, lds, bin_base, n, out); break;
       case 7: rank_sort<7>(P, lds, bin_base, n, out); break;
       default: rank_sort<8>(P, lds, bin_base, n, out); break;
+#else
+      default: rank_sort_big(P, lds, marks, bin_base, n, out); break;
+#endif
     }
     __threadfence_block();
     __syncthreads();
@@ -715,6 +818,19 @@ __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned l
   __syncthreads();
 }
 
+// LDS block of a tile workgroup (s_c), by phase:
+//   [0, 8K)    phase A: the (depth << 32 | key) tile.  From phase B on: the tile's colour, row-major, in the
+//              target's encoding — shaded pixels go straight there instead of living in registers until the
+//              write-back (with depth, keys and colours of four pixels per lane in VGPRs the kernel sat on the
+//              128-register line and every change to the fragment stage paid in scratch traffic)
+//   [8K, 12K)  the tile's opaque depth bits for phase C's depth test (phase A of a quarter: its triangle list, to 28K)
+//   [12K, 28K) phase C: sort scratch, then per wave its fragment queue | lane mask per pixel | shaded colours
+constexpr uint32_t LDS_Z_OFF = TILE * TILE * 8;
+constexpr uint32_t LDS_C_OFF = LDS_Z_OFF + TILE * TILE * 4;
+constexpr uint32_t WAVE_C_BYTES = QUEUE_CAP * 8 + 256 * 8 + 64 * 16;  // queue | lane mask per pixel | shaded colours
+constexpr uint32_t PHASE_C_BYTES = LDS_C_OFF + 4 * WAVE_C_BYTES;
+constexpr uint32_t REC_COMMON = 0x80000000u;  // in a lane's winning record index: the key's common-case bit (record indices stay below 2^31)
+
 // QUARTER: this workgroup renders 8 rows of a split tile (svr_device.h SPLIT_*).  Its own instantiation, chosen
 // by blockIdx alone: sharing one body with run-time row ranges cost the whole-tile path 20-35 spilled
 // registers and 8-13 % of the frame, and choosing by a flag in tile_info put a dependent load in front of
@@ -742,40 +858,44 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
   const int row0 = QUARTER ? (int)(rows & 0xffu) : 0;
   constexpr uint32_t lrpw = QUARTER ? 1u : 3u;  // log2(rows per wave in phase C)
   constexpr int nrows = 4 << lrpw;
-  uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-  uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  int ox = (int)(P.sx + tx * TILE + (wave & 1u) * 16u), oy = (int)(P.sy + ty * TILE + (wave >> 1) * 16u);
-  int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
-  int x_end = (int)(P.sx + P.sw), y_end = (int)(P.sy + P.sh);
+  const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const int tx0 = (int)(P.sx + tx * TILE), ty0 = (int)(P.sy + ty * TILE);
+  const int x_end = (int)(P.sx + P.sw), y_end = (int)(P.sy + P.sh);
+  const int sub_y0 = ty0 + row0;
+  // pixel ownership: wave w the 16x16 quadrant w, lane l one pixel in each of its four 8x8 blocks; slot k of a
+  // lane is the pixel (rx + (k & 1) * 8, ry + (k >> 1) * 8) of the tile, word li + (k & 1) * 8 + (k >> 1) * 256 of its LDS images
+  const int rx = (int)((wave & 1u) * 16u + (lane & 7u)), ry = (int)((wave >> 1) * 16u + (lane >> 3));
+  const uint32_t li = (uint32_t)ry * TILE + (uint32_t)rx;
+  // the whole tile lies inside the scissor (every pixel of it is this workgroup's to write): wave-uniform
+  const bool inside = !QUARTER && tx0 + TILE <= x_end && ty0 + TILE <= y_end;
+  const bool aligned = ((P.W | P.sx) & 3u) == 0u;
 
-  const int sub_y0 = (int)(P.sy + ty * TILE) + row0;
   bool pix_ok[4];
-  uint32_t zbits[4], keys[4], recs[4], zero4[4];
+  uint32_t recs[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
+    int px = tx0 + rx + (k & 1) * 8, py = ty0 + ry + (k >> 1) * 8;
     pix_ok[k] = px < x_end && py < y_end && (!QUARTER || (uint32_t)(py - sub_y0) < (uint32_t)nrows);
-    zbits[k] = 0u;  // depth CLEAR 0.0
-    keys[k] = 0u;
     recs[k] = NO_REC;
-    zero4[k] = 0u;
   }
   uint32_t n_raster = 0, n_shaded = 0;
   long long stamp[5] = {0, 0, 0, 0, 0};  // SVR_OPT_TILE_CYCLES: shader-clock stamps per phase
   const bool stamps = P.tile_cycles != nullptr;
   if (stamps) stamp[0] = clock64();
 
+  unsigned long long* s_depth = reinterpret_cast<unsigned long long*>(s_c);
+  enc_t* lc = reinterpret_cast<enc_t*>(s_c);
+  uint32_t* s_z = reinterpret_cast<uint32_t*>(s_c + LDS_Z_OFF);
+
   // ---- phase A: opaque visibility
   if (n_op) {
-    unsigned long long* s_depth = reinterpret_cast<unsigned long long*>(s_c);  // 8 KiB of the phase-C block
-    int tx0 = (int)(P.sx + tx * TILE), ty0 = (int)(P.sy + ty * TILE);
     for (uint32_t i = threadIdx.x; i < TILE * TILE; i += 256u) s_depth[i] = 0ull;  // ordered by scan_columns' first barrier
     if (QUARTER && n_op > 2u * BATCH && n_op <= QUARTER_LIST_CAP) {
       // A quarter of an opaque-heavy tile: most of the bin's triangles do not reach its 8 rows, and staging
       // them costs as much as in the whole tile.  One pass over the record headers (indices, then bounding
       // rows: two round trips per 1024 entries) leaves the quarter's own list in LDS, behind the depth tile.
-      uint32_t* s_list = reinterpret_cast<uint32_t*>(s_c + TILE * TILE * 8);
-      const uint32_t lane_ = threadIdx.x & 63u;
+      uint32_t* s_list = reinterpret_cast<uint32_t*>(s_c + LDS_Z_OFF);
       if (threadIdx.x == 0) s_idx[0] = 0u;
       __syncthreads();
       for (uint32_t base = 0; base < n_op; base += 1024u) {
@@ -798,9 +918,9 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
           bool keep = i < n_op && maxy >= sub_y0 && miny <= sub_y0 + nrows - 1;
           unsigned long long m = __ballot(keep);
           uint32_t at = 0;
-          if (lane_ == 0 && m) at = atomicAdd(&s_idx[0], (uint32_t)__popcll(m));  // LDS
+          if (lane == 0 && m) at = atomicAdd(&s_idx[0], (uint32_t)__popcll(m));  // LDS
           at = __shfl(at, 0);
-          if (keep) s_list[at + (uint32_t)__popcll(m & ((1ull << lane_) - 1ull))] = ri[k];
+          if (keep) s_list[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ri[k];
         }
       }
       __syncthreads();
@@ -810,44 +930,58 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
       scan_columns<INSTR, false>(P, s_cov, nullptr, off_op, n_op, s_depth, tx0, ty0, QUARTER ? sub_y0 : ty0, nrows, n_raster);
     }
     __syncthreads();
-    // (the pixel's place in the tile is recomputed from the thread index behind a compiler barrier: kept live
-    // across the scan it was spilled to scratch, and the two reloads stood in front of every tile's phase B)
-    uint32_t tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int rx0 = (int)(((tid >> 6) & 1u) * 16u + (tid & 7u)), ry0 = (int)((tid >> 7) * 16u + ((tid >> 3) & 7u));
 #pragma unroll
-    for (int k = 0; k < 4; k++) {  // the winners move into the owning lanes' registers
-      int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
-      unsigned long long v = s_depth[(ry0 + (k >> 1) * 8) * TILE + rx0 + (k & 1) * 8];
+    for (int k = 0; k < 4; k++) {  // the winners' records move into the owning lanes' registers
+      unsigned long long v = s_depth[li + (uint32_t)((k & 1) * 8 + (k >> 1) * 256)];
       if ((uint32_t)v != 0u) {
-        zbits[k] = (uint32_t)(v >> 32);
-        keys[k] = (uint32_t)v;
         uint32_t main_slot = ((uint32_t)v >> 2) - 1u;
-        recs[k] = ((uint32_t)v & 1u) ? resolve_record(P, main_slot, px, py) : main_slot;
+        uint32_t rec = ((uint32_t)v & 1u) ? resolve_record(P, main_slot, tx0 + rx + (k & 1) * 8, ty0 + ry + (k >> 1) * 8) : main_slot;
+        recs[k] = rec | (((uint32_t)v & 2u) ? REC_COMMON : 0u);
       }
     }
-    if (n_tr) __syncthreads();  // phase C reuses the block at once (phase D's own barrier covers the other case)
   }
+  // The depth target is final here (transparent fragments test but do not write, src/vk_engine.cpp:1673-1674):
+  // it leaves now, straight from the visibility tile, as whole rows where the tile lies inside the scissor (16
+  // bytes per lane, full 128-byte lines), and phase C's copy of the opaque depth is taken on the way.
+  if (inside && aligned) {
+    const uint32_t row = threadIdx.x >> 3, c = (threadIdx.x & 7u) * 4u;
+    uint4 z = make_uint4(0u, 0u, 0u, 0u);  // depth CLEAR 0.0
+    if (n_op) {
+      const uint4* src = reinterpret_cast<const uint4*>(s_depth + row * TILE + c);
+      uint4 lo = src[0], hi = src[1];
+      z = make_uint4(lo.y, lo.w, hi.y, hi.w);
+    }
+    *reinterpret_cast<uint4*>(P.depth + (size_t)(ty0 + (int)row) * P.W + (size_t)(tx0 + (int)c)) = z;
+    if (n_tr) *reinterpret_cast<uint4*>(s_z + row * TILE + c) = z;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t w = li + (uint32_t)((k & 1) * 8 + (k >> 1) * 256);
+      uint32_t z = n_op ? (uint32_t)(s_depth[w] >> 32) : 0u;
+      if (pix_ok[k]) P.depth[(size_t)(ty0 + ry + (k >> 1) * 8) * P.W + (size_t)(tx0 + rx + (k & 1) * 8)] = u2f(z);
+      if (n_tr) s_z[w] = z;
+    }
+  }
+  __syncthreads();  // the visibility tile is dead: its memory is the tile's colour from here on
 
   if (stamps) stamp[1] = clock64();
-  // ---- phase B: shade visible pixels once
-  enc_t enc[4];
+  // ---- phase B: shade visible pixels once, into the LDS colour tile
   bool dirty[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    dirty[k] = recs[k] != NO_REC;
-    enc[k] = enc_t();
-  }
+  for (int k = 0; k < 4; k++) dirty[k] = recs[k] != NO_REC;
   uint32_t generic_slots = 0;  // wave-uniform: pixel slots in which some lane needs the generic fragment stage
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
-    if (__all(!dirty[k] || (keys[k] & 2u))) {  // every shaded pixel of the wave is the common case
+    uint32_t tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int qx = (int)(((tid >> 6) & 1u) * 16u + (tid & 7u)) + (k & 1) * 8, qy = (int)((tid >> 7) * 16u + ((tid >> 3) & 7u)) + (k >> 1) * 8;
+    const int px = tx0 + qx, py = ty0 + qy;
+    if (__all(!dirty[k] || (recs[k] & REC_COMMON))) {
       if (dirty[k]) {
-        enc[k] = CD::encode(shade_pixel<false, true>(P, recs[k], px, py, nullptr));
+        lc[(uint32_t)qy * TILE + (uint32_t)qx] = CD::encode(shade_pixel<false, true>(P, recs[k] & ~REC_COMMON, px, py, nullptr));
         if (INSTR) {
           n_shaded++;
-          if (P.trace_buf && px == P.trace_x && py == P.trace_y) (void)shade_pixel<true>(P, recs[k], px, py, P.trace_buf);
+          if (P.trace_buf && px == P.trace_x && py == P.trace_y) (void)shade_pixel<true>(P, recs[k] & ~REC_COMMON, px, py, P.trace_buf);
         }
       }
     } else {
@@ -861,15 +995,11 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
 #pragma unroll 1
     for (int k = 0; k < 4; k++) {
       if (!((generic_slots >> k) & 1u)) continue;
-      uint32_t rec = k == 0 ? recs[0] : (k == 1 ? recs[1] : (k == 2 ? recs[2] : recs[3]));
+      uint32_t rec = (k == 0 ? recs[0] : (k == 1 ? recs[1] : (k == 2 ? recs[2] : recs[3]))) & ~REC_COMMON;
       bool d = k == 0 ? dirty[0] : (k == 1 ? dirty[1] : (k == 2 ? dirty[2] : dirty[3]));
-      int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
+      int px = tx0 + rx + (k & 1) * 8, py = ty0 + ry + (k >> 1) * 8;
       if (d) {
-        enc_t e = CD::encode(shade_pixel<false>(P, rec, px, py, nullptr));
-        enc[0] = k == 0 ? e : enc[0];
-        enc[1] = k == 1 ? e : enc[1];
-        enc[2] = k == 2 ? e : enc[2];
-        enc[3] = k == 3 ? e : enc[3];
+        lc[li + (uint32_t)((k & 1) * 8 + (k >> 1) * 256)] = CD::encode(shade_pixel<false>(P, rec, px, py, nullptr));
         if (INSTR) {
           n_shaded++;
           if (P.trace_buf && px == P.trace_x && py == P.trace_y) (void)shade_pixel<true>(P, rec, px, py, P.trace_buf);
@@ -885,7 +1015,7 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
 #pragma unroll
     for (int k = 0; k < 4; k++)
       if (!dirty[k] && pix_ok[k]) {
-        enc[k] = cv;
+        lc[li + (uint32_t)((k & 1) * 8 + (k >> 1) * 256)] = cv;
         dirty[k] = true;
       }
   }
@@ -893,69 +1023,42 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
   // ---- phase C: transparent fragments in submission order
   if (n_tr) {
     uint32_t tbase = off_tr;
-    int tx0 = (int)(P.sx + tx * TILE), ty0 = (int)(P.sy + ty * TILE);
     const uint32_t* order = P.bins + tbase;
+    unsigned long long* scratch = reinterpret_cast<unsigned long long*>(s_c + LDS_C_OFF);
     if (QUARTER) {  // n_tr <= SORT_CAP: sorted in LDS, written out of place
       uint32_t* shared_list = reinterpret_cast<uint32_t*>(P.sort_arena + sort_base);
-      sort_bin_by_key(P, reinterpret_cast<unsigned long long*>(s_c), tbase, n_tr, shared_list);
+      sort_bin_by_key(P, scratch, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, shared_list);
       order = shared_list;
     } else if (n_tr <= SORT_CAP) {
-      sort_bin_by_key(P, reinterpret_cast<unsigned long long*>(s_c), tbase, n_tr, P.bins + tbase);
+      sort_bin_by_key(P, scratch, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, P.bins + tbase);
     } else {
-      sort_bin_by_key(P, P.sort_arena + sort_base, tbase, n_tr, P.bins + tbase);  // rare: a bin too large for LDS
+      sort_bin_by_key(P, P.sort_arena + sort_base, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, P.bins + tbase);  // rare: a bin too large for LDS
     }
-    uint32_t* s_z = reinterpret_cast<uint32_t*>(s_c + 4 * WAVE_C_BYTES);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {  // owners publish colour and opaque depth of their pixels to the row bands
-      int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
-      size_t p = (size_t)py * P.W + (size_t)px;
-      enc_t c = enc[k];
-      if (!dirty[k] && pix_ok[k]) c = reinterpret_cast<const enc_t*>(P.color)[p];  // colour loadOp LOAD
-      int ry = py - ty0, rx = px - tx0, rr = ry - row0;
-      if (!QUARTER || (uint32_t)rr < (uint32_t)nrows) reinterpret_cast<enc_t*>(s_c + (rr >> lrpw) * WAVE_C_BYTES)[(rr & ((1 << lrpw) - 1)) * TILE + rx] = c;
-      s_z[ry * TILE + rx] = zbits[k];
-    }
-    unsigned char* mine = s_c + wave * WAVE_C_BYTES;
-    enc_t* col = reinterpret_cast<enc_t*>(mine);
-    uint2* q = reinterpret_cast<uint2*>(mine + 256 * 8);
-    unsigned long long* mask = reinterpret_cast<unsigned long long*>(mine + 256 * 8 + QUEUE_CAP * 8);
-    float4* s_src = reinterpret_cast<float4*>(mine + 256 * 8 + QUEUE_CAP * 8 + 256 * 8);
+    for (int k = 0; k < 4; k++)  // colour loadOp LOAD for what neither the opaque pass nor a clear has written
+      if (!dirty[k] && pix_ok[k])
+        lc[li + (uint32_t)((k & 1) * 8 + (k >> 1) * 256)] =
+            reinterpret_cast<const enc_t*>(P.color)[(size_t)(ty0 + ry + (k >> 1) * 8) * P.W + (size_t)(tx0 + rx + (k & 1) * 8)];
+    unsigned char* mine = s_c + LDS_C_OFF + wave * WAVE_C_BYTES;
+    enc_t* col = lc + (uint32_t)(row0 + ((int)wave << lrpw)) * TILE;  // this wave's rows of the colour tile
+    uint2* q = reinterpret_cast<uint2*>(mine);
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(mine + QUEUE_CAP * 8);
+    float4* s_src = reinterpret_cast<float4*>(mine + QUEUE_CAP * 8 + 256 * 8);
     for (uint32_t i = lane; i < 256u; i += 64u) mask[i] = 0ull;
     // (the first barrier inside the scan orders these writes)
     scan_columns_ordered<FMT, INSTR>(P, s_cov, s_idx, order, n_tr, tx0, ty0, row0, lrpw, s_z, col, q, mask, s_src, n_raster, n_shaded);
-    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int rr = oy + (k >> 1) * 8 + ly - ty0 - row0, rx = ox + (k & 1) * 8 + lx - tx0;
-      if (!QUARTER || (uint32_t)rr < (uint32_t)nrows) enc[k] = reinterpret_cast<const enc_t*>(s_c + (rr >> lrpw) * WAVE_C_BYTES)[(rr & ((1 << lrpw) - 1)) * TILE + rx];
-      dirty[k] = pix_ok[k];
-    }
+    for (int k = 0; k < 4; k++) dirty[k] = pix_ok[k];
   }
 
   if (stamps) stamp[3] = clock64();
-  // ---- phase D: write back
-  // A tile that lies inside the scissor and has every pixel written goes out through LDS as whole
-  // rows: 16 bytes per lane, every 128-byte line of the tile's rows written by one instruction.  (A
-  // lane's own pixels are 8-pixel row pieces of four 8x8 blocks: stored directly they reach memory as
-  // 32- and 64-byte partial lines, which the memory side counted as twice the bytes.)
-  const bool whole = pix_ok[0] && pix_ok[1] && pix_ok[2] && pix_ok[3] && dirty[0] && dirty[1] && dirty[2] && dirty[3];
-  const bool aligned = ((P.W | P.sx) & 3u) == 0u;
-  if (__syncthreads_and(whole) && aligned) {  // the barrier also retires phase C's use of the block
-    const int tx0 = (int)(P.sx + tx * TILE), ty0 = (int)(P.sy + ty * TILE);
-    enc_t* lc = reinterpret_cast<enc_t*>(s_c);
-    uint32_t* lz = reinterpret_cast<uint32_t*>(s_c + TILE * TILE * sizeof(enc_t));
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int ry = oy + (k >> 1) * 8 + ly - ty0, rx = ox + (k & 1) * 8 + lx - tx0;
-      lc[ry * TILE + rx] = enc[k];
-      lz[ry * TILE + rx] = zbits[k];
-    }
-    __syncthreads();
-    {
-      uint32_t row = threadIdx.x >> 3, c = (threadIdx.x & 7u) * 4u;  // 4 depth values per lane
-      uint4 v = *reinterpret_cast<const uint4*>(lz + row * TILE + c);
-      *reinterpret_cast<uint4*>(P.depth + (size_t)(ty0 + (int)row) * P.W + (size_t)(tx0 + (int)c)) = v;
-    }
+  // ---- phase D: the colour tile goes out (the barrier retires phase B's and phase C's writes to it)
+  // A tile that lies inside the scissor and has every pixel written leaves as whole rows: 16 bytes per
+  // lane, every 128-byte line of the tile's rows written by one instruction.  (A lane's own pixels are
+  // 8-pixel row pieces of four 8x8 blocks: stored directly they reach memory as 32- and 64-byte partial
+  // lines, which the memory side counted as twice the bytes.)
+  const bool whole = dirty[0] && dirty[1] && dirty[2] && dirty[3];
+  if (__syncthreads_and(whole) && inside && aligned) {
     constexpr uint32_t PX = 16u / sizeof(enc_t);  // pixels per 16-byte store
 #pragma unroll
     for (uint32_t i = threadIdx.x; i < TILE * TILE / PX; i += 256u) {
@@ -965,13 +1068,10 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
     }
   } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (!pix_ok[k]) continue;
-      int px = ox + (k & 1) * 8 + lx, py = oy + (k >> 1) * 8 + ly;
-      size_t p = (size_t)py * P.W + (size_t)px;
-      P.depth[p] = u2f(zbits[k]);
-      if (dirty[k]) reinterpret_cast<enc_t*>(P.color)[p] = enc[k];
-    }
+    for (int k = 0; k < 4; k++)
+      if (pix_ok[k] && dirty[k])
+        reinterpret_cast<enc_t*>(P.color)[(size_t)(ty0 + ry + (k >> 1) * 8) * P.W + (size_t)(tx0 + rx + (k & 1) * 8)] =
+            lc[li + (uint32_t)((k & 1) * 8 + (k >> 1) * 256)];
   }
   if (stamps) {
     stamp[4] = clock64();
@@ -993,13 +1093,17 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
 // SPLIT: the launch is headed by SPLIT_EXTRA slots for the quarters of split tiles.  A kernel of its own: the
 // quarter path merely compiled in costs the whole-tile path 2-3 % (registers, code size), which a pass with
 // more than SPLIT_TILES_MAX tiles — where no tile is worth splitting — need not pay.
+#ifndef SVR_TILE_WAVES
+#define SVR_TILE_WAVES 4  // workgroups per CU the tile kernel is compiled for (A/B builds: tools/build_variant.sh)
+#endif
 template <int FMT, bool INSTR, bool SPLIT>
-__global__ __launch_bounds__(256, 4) void tile_kernel(FrameParams P) {
+__global__ __launch_bounds__(256, SVR_TILE_WAVES) void tile_kernel(FrameParams P) {
   __shared__ uint4 s_cov[BATCH * 8];
   __shared__ uint32_t s_idx[BATCH];
   __shared__ __attribute__((aligned(16))) unsigned char s_c[PHASE_C_BYTES];  // phase A depth tile, phase C blocks
-  static_assert(TILE * TILE * 8 + QUARTER_LIST_CAP * 4 <= PHASE_C_BYTES, "depth tile + a quarter's triangle list");
-  static_assert(SPLIT_SORT_MAX <= SORT_CAP && PHASE_C_BYTES >= SORT_CAP * 8 && PHASE_C_BYTES >= TILE * TILE * 8, "sort scratch and depth tile alias the block");
+  static_assert(LDS_Z_OFF + QUARTER_LIST_CAP * 4 <= PHASE_C_BYTES, "depth tile + a quarter's triangle list");
+  static_assert(SPLIT_SORT_MAX <= SORT_CAP && 4 * WAVE_C_BYTES >= SORT_CAP * 8 && 4 * WAVE_C_BYTES >= RANK_SORT_MAX * 8, "sort scratch aliases the waves' phase-C blocks");
+  static_assert(TILE * TILE * 8 >= TILE * TILE * sizeof(uint2), "the colour tile aliases the visibility tile");
 
   // Everything the workgroup needs before it can start comes in ONE round of scalar loads: the failure flags
   // and the launch slot's tile_info.  (Written as plain loads they compiled to a chain of four round trips
@@ -1063,7 +1167,9 @@ void launch_tiles(const FrameParams& P, int color_format, bool count_fragments, 
   dim3 grid(split ? P.n_tiles + SPLIT_EXTRA : P.n_tiles), block(256);
   const bool report = count_fragments || P.flatten;
   hipEvent_t tile_done = report ? nullptr : done;
-#define SVR_LAUNCH_TILES(FMT, INSTR, SPLIT) hipExtLaunchKernelGGL((tile_kernel<FMT, INSTR, SPLIT>), grid, block, 0, s, start, tile_done, 0, P)
+  // SVR_TILE_LDS_PAD (development): extra dynamic LDS per workgroup, i.e. fewer workgroups per CU without a rebuild
+  static const uint32_t lds_pad = [] { const char* e = getenv("SVR_TILE_LDS_PAD"); return e ? (uint32_t)atoi(e) : 0u; }();
+#define SVR_LAUNCH_TILES(FMT, INSTR, SPLIT) hipExtLaunchKernelGGL((tile_kernel<FMT, INSTR, SPLIT>), grid, block, lds_pad, s, start, tile_done, 0, P)
   if (color_format == SVR_COLOR_RGBA16F) {
     if (count_fragments) {
       if (split) SVR_LAUNCH_TILES(SVR_COLOR_RGBA16F, true, true);

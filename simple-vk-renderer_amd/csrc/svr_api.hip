@@ -66,7 +66,8 @@ struct MeshRes {
   bool alive = false;
 };
 struct ImageRes {
-  uint8_t* base = nullptr;
+  uint32_t arena_off = 0;   // byte offset of level 0 in the context's texel arena
+  size_t bytes = 0;         // all levels
   uint32_t w = 0, h = 0, levels = 0;
   uint32_t lw = 0, lh = 0;  // log2 of the power-of-two padded extent the mip layout is computed from
   uint32_t off[16] = {0};   // = mip_offset(lw, lh, level)
@@ -115,6 +116,14 @@ struct SvrContext {
   std::vector<ImageRes> images;
   std::vector<SvrSamplerDesc> samplers;
   std::vector<MaterialRes> materials;
+  // Texel arena: every image of the context lives in ONE allocation, so a texel's address is a 32-bit byte
+  // offset from one wave-uniform base (FrameParams::tex_arena): the fragment stage's eight gathers per pixel
+  // are global loads with an SGPR base and a 32-bit VGPR offset instead of 64-bit pointer arithmetic per tap,
+  // and records carry 4 bytes per texture, not a pointer.  Grows by reallocation (device copy, after a
+  // fence); offsets never change.  Bound: 4 GiB of texels per context.
+  uint8_t* tex_arena = nullptr;
+  size_t tex_arena_cap = 0, tex_arena_top = 0;
+  std::vector<std::pair<size_t, size_t>> tex_holes;  // (offset, bytes) of destroyed images, sorted by offset
   DevBuf tex_table;  // TexBinding[materials + 1]; last slot = scratch binding of svr_draw_tex_image
   size_t tex_slots = 0;
   // resource tables of the device flatten pass (k_flatten.hip), rebuilt when a mesh / material was added
@@ -222,12 +231,76 @@ TexBinding make_binding(const ImageRes& im, const SvrSamplerDesc& s) {
   TexBinding tb;
   std::memset(&tb, 0, sizeof(tb));
   uint32_t filters = (uint32_t)s.mag_filter | ((uint32_t)s.min_filter << 1) | ((uint32_t)s.mipmap_mode << 2);
-  tb.base = im.base;
+  tb.base_off = im.arena_off;
   tb.wh = im.w | (im.h << 16);
   tb.info = im.lw | (im.lh << 8) | (im.levels << 16) | (filters << 24);
   tb.min_lod = s.min_lod;
   tb.max_lod = s.max_lod;
   return tb;
+}
+
+// ---------------------------------------------------------------- texel arena
+int finish_pending(SvrContext* ctx);
+
+constexpr size_t ARENA_MAX = (size_t)0xffffff00u;  // offsets are 32-bit
+constexpr size_t ARENA_ALIGN = 256;
+
+int arena_alloc(SvrContext* ctx, size_t bytes, uint32_t* off) {
+  bytes = (bytes + ARENA_ALIGN - 1) & ~(ARENA_ALIGN - 1);
+  for (size_t i = 0; i < ctx->tex_holes.size(); i++) {  // first fit among the holes
+    auto& h = ctx->tex_holes[i];
+    if (h.second >= bytes) {
+      *off = (uint32_t)h.first;
+      h.first += bytes;
+      h.second -= bytes;
+      if (h.second == 0) ctx->tex_holes.erase(ctx->tex_holes.begin() + (long)i);
+      return SVR_OK;
+    }
+  }
+  if (ctx->tex_arena_top + bytes > ARENA_MAX)
+    return fail(SVR_ERR_OUT_OF_MEMORY, "svr_create_image: more than 4 GiB of texels in one context");
+  if (ctx->tex_arena_top + bytes > ctx->tex_arena_cap) {
+    // grow: passes in flight read the old arena, so this is a fence; offsets stay valid
+    size_t want = std::max(ctx->tex_arena_cap * 2, ctx->tex_arena_top + bytes);
+    want = std::min(ARENA_MAX, (want + ((size_t)64 << 20) - 1) & ~(((size_t)64 << 20) - 1));
+    if (int e = finish_pending(ctx)) return e;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    uint8_t* grown = nullptr;
+    HIPCHK(hipMalloc((void**)&grown, want));
+    if (ctx->tex_arena_top) {
+      hipError_t r = hipMemcpy(grown, ctx->tex_arena, ctx->tex_arena_top, hipMemcpyDeviceToDevice);
+      if (r != hipSuccess) {
+        (void)hipFree(grown);
+        return fail(SVR_ERR_DEVICE, std::string("hipMemcpy(texel arena): ") + hipGetErrorString(r));
+      }
+    }
+    if (ctx->tex_arena) (void)hipFree(ctx->tex_arena);
+    ctx->tex_arena = grown;
+    ctx->tex_arena_cap = want;
+  }
+  *off = (uint32_t)ctx->tex_arena_top;
+  ctx->tex_arena_top += bytes;
+  return SVR_OK;
+}
+
+void arena_free(SvrContext* ctx, size_t off, size_t bytes) {
+  bytes = (bytes + ARENA_ALIGN - 1) & ~(ARENA_ALIGN - 1);
+  auto& holes = ctx->tex_holes;
+  size_t i = 0;
+  while (i < holes.size() && holes[i].first < off) i++;
+  holes.insert(holes.begin() + (long)i, std::make_pair(off, bytes));
+  if (i + 1 < holes.size() && holes[i].first + holes[i].second == holes[i + 1].first) {  // merge with the next
+    holes[i].second += holes[i + 1].second;
+    holes.erase(holes.begin() + (long)i + 1);
+  }
+  if (i > 0 && holes[i - 1].first + holes[i - 1].second == holes[i].first) {  // and the previous
+    holes[i - 1].second += holes[i].second;
+    holes.erase(holes.begin() + (long)i);
+  }
+  if (!holes.empty() && holes.back().first + holes.back().second == ctx->tex_arena_top) {  // a hole at the top is no hole
+    ctx->tex_arena_top = holes.back().first;
+    holes.pop_back();
+  }
 }
 
 // (re)upload the binding table: one slot per material + one scratch slot
@@ -657,6 +730,7 @@ int fill_frame_params(SvrContext* ctx, const SvrSceneData* scene, uint64_t n_tri
   P.n_tris = (uint32_t)n_tris64;
   P.n_chunks = (uint32_t)n_chunks;
   P.tex = (const TexBinding*)ctx->tex_table.p;
+  P.tex_arena = ctx->tex_arena;
   P.instrument = ctx->instrument ? 1u : 0u;
   P.trace_x = ctx->trace_x;
   P.trace_y = ctx->trace_y;
@@ -849,8 +923,7 @@ void svr_destroy(SvrContext* ctx) {
     if (m.vtx) (void)hipFree(m.vtx);
     if (m.idx) (void)hipFree(m.idx);
   }
-  for (auto& im : ctx->images)
-    if (im.base) (void)hipFree(im.base);
+  if (ctx->tex_arena) (void)hipFree(ctx->tex_arena);
   DevBuf* bufs[] = {&ctx->tex_table, &ctx->d_cvt, &ctx->d_trace, &ctx->d_tile_cycles, &ctx->mesh_table, &ctx->mat_table};
   for (auto& set : ctx->sets) {
     DevBuf* sb[] = {&set.inputs, &set.recs, &set.clipq, &set.bigq, &set.tiles, &set.bins, &set.pairs, &set.flat, &set.sorta};
@@ -973,10 +1046,12 @@ int svr_create_image(SvrContext* ctx, const void* rgba8, uint32_t width, uint32_
   size_t total = (size_t)mip_offset(im.lw, im.lh, im.levels - 1) +
                  (size_t)std::max(1u, width >> (im.levels - 1)) * std::max(1u, height >> (im.levels - 1)) * 4;
   if (im.lw + im.lh > 28) return fail(SVR_ERR_UNSUPPORTED, "svr_create_image: image larger than 1 GiB");
-  HIPCHK(hipMalloc((void**)&im.base, std::max<size_t>(total, 256)));
-  hipError_t r = hipMemcpy(im.base, rgba8, (size_t)width * height * 4, hipMemcpyHostToDevice);
+  im.bytes = std::max<size_t>(total, 256);
+  if (int e = arena_alloc(ctx, im.bytes, &im.arena_off)) return e;
+  uint8_t* base = ctx->tex_arena + im.arena_off;
+  hipError_t r = hipMemcpy(base, rgba8, (size_t)width * height * 4, hipMemcpyHostToDevice);
   if (r != hipSuccess) {
-    (void)hipFree(im.base);
+    arena_free(ctx, im.arena_off, im.bytes);
     return fail(SVR_ERR_DEVICE, std::string("hipMemcpy(image): ") + hipGetErrorString(r));
   }
   // generate_mipmaps: level n -> n+1, each a 2:1 linear blit (src/vk_images.cpp:66-133)
@@ -984,7 +1059,7 @@ int svr_create_image(SvrContext* ctx, const void* rgba8, uint32_t width, uint32_
   lh = height;
   for (uint32_t l = 1; l < im.levels; l++) {
     uint32_t dw = std::max(1u, lw >> 1), dh = std::max(1u, lh >> 1);
-    launch_downsample(im.base + im.off[l - 1], lw, lh, im.base + im.off[l], dw, dh, ctx->stream);
+    launch_downsample(base + im.off[l - 1], lw, lh, base + im.off[l], dw, dh, ctx->stream);
     lw = dw;
     lh = dh;
   }
@@ -1001,8 +1076,7 @@ int svr_destroy_image(SvrContext* ctx, SvrImage image) {
   if (!im) return fail(SVR_ERR_BAD_HANDLE, "svr_destroy_image: bad handle");
   if (int e = use_device(ctx)) return e;
   if (int e = finish_pending(ctx)) return e;
-  (void)hipFree(im->base);
-  im->base = nullptr;
+  arena_free(ctx, im->arena_off, im->bytes);
   im->alive = false;
   return SVR_OK;
 }
@@ -1019,7 +1093,7 @@ int svr_read_image_level(SvrContext* ctx, SvrImage image, uint32_t level, void* 
     size_t need = (size_t)lw * lh * 4;
     if (bytes < need) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_read_image_level: buffer too small");
     if (int e = use_device(ctx)) return e;
-    HIPCHK(hipMemcpy(dst, im->base + im->off[level], need, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dst, ctx->tex_arena + im->arena_off + im->off[level], need, hipMemcpyDeviceToHost));
   }
   return SVR_OK;
 }
@@ -1429,6 +1503,29 @@ int svr_debug_read_tile_cycles(SvrContext* ctx, uint32_t* cycles, size_t capacit
     return fail(SVR_ERR_INVALID_ARGUMENT, "svr_debug_read_tile_cycles: SVR_OPT_TILE_CYCLES was off for the last pass or buffer too small");
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(cycles, ctx->last.tile_cycles, 16 * (size_t)ctx->last.n_tiles, hipMemcpyDeviceToHost));
+  return SVR_OK;
+}
+
+int svr_debug_rcp_sweep(SvrContext* ctx, int variant, uint64_t first, uint64_t count, uint64_t* mismatches, uint64_t* refined,
+                        uint32_t first_bad[16]) {
+  if (!ctx || !mismatches) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_debug_rcp_sweep: null argument");
+  if (variant < 0 || variant > 2 || first + count > (1ull << 32)) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_debug_rcp_sweep: bad range or variant");
+  if (int e = use_device(ctx)) return e;
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, 19 * 8));
+  unsigned long long h[19] = {};
+  hipError_t r = hipMemset(d, 0, 19 * 8);
+  if (r == hipSuccess) {
+    launch_rcp_sweep(variant, first, count, d, ctx->stream);
+    r = hipStreamSynchronize(ctx->stream);
+  }
+  if (r == hipSuccess) r = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (r != hipSuccess) return fail(SVR_ERR_DEVICE, std::string("svr_debug_rcp_sweep: ") + hipGetErrorString(r));
+  *mismatches = h[0];
+  if (refined) *refined = h[1];
+  if (first_bad)
+    for (int k = 0; k < 16; k++) first_bad[k] = (uint32_t)h[2 + k];
   return SVR_OK;
 }
 

@@ -14,6 +14,9 @@ constexpr int TILE_SHIFT = 5;
 constexpr int WAVE = 64;
 constexpr float GUARD = 16384.0f;  // guard band in pixels (C3)
 constexpr uint32_t NO_REC = 0xffffffffu;
+#ifndef SVR_RCP_VARIANT
+#define SVR_RCP_VARIANT 1
+#endif
 
 enum PipelineKind : uint32_t { PIPE_MESH = 0, PIPE_COLORED_TRIANGLE = 1, PIPE_TEX_IMAGE = 2 };
 
@@ -72,7 +75,8 @@ struct WaveChunk {
 // out as if the image were padded to 2^lw x 2^lh, so the offset is a closed form), row pitch =
 // the level's true width max(w >> l, 1).
 struct TexBinding {
-  const uint8_t* base;      // RGBA8 texels of level 0
+  uint32_t base_off;        // RGBA8 texels of level 0: byte offset in the context's texel arena (FrameParams::tex_arena)
+  uint32_t pad0;
   uint32_t wh;              // w | h << 16   (extent <= 16384 each)
   uint32_t info;            // lw | lh << 8 | levels << 16 | filters << 24; filters = mag | min<<1 | mip<<2
   float min_lod, max_lod;
@@ -105,7 +109,7 @@ struct TriRec {
   uint32_t flags;
   float z0, dz1, dz2, inv_area;
   double A[3], B[3], C[3];
-  const uint8_t* tex_base;         // the draw's TexBinding, copied in (offset 104)
+  uint32_t tex_off, tex_pad;       // the draw's TexBinding, copied in (offset 104): arena offset of level 0
   uint32_t tex_wh, tex_info;
   float tex_min_lod, tex_max_lod;
   // ---- shading half
@@ -114,7 +118,7 @@ struct TriRec {
   float pad2[5];
 };
 static_assert(sizeof(TriRec) == 256, "TriRec layout");
-static_assert(offsetof(TriRec, A) == 32 && offsetof(TriRec, tex_base) == 104 && offsetof(TriRec, tex_wh) == 112 &&
+static_assert(offsetof(TriRec, A) == 32 && offsetof(TriRec, tex_off) == 104 && offsetof(TriRec, tex_wh) == 112 &&
                   offsetof(TriRec, q0) == 128, "TriRec layout");
 
 struct ClipItem {
@@ -195,6 +199,7 @@ struct FrameParams {
   uint32_t bin_cap;
   Counters* counters;
   const TexBinding* tex;
+  const uint8_t* tex_arena;       // every image of the context: texel addresses are this + a 32-bit offset
   uint32_t instrument;            // count fragments/triangles with device atomics (not in timed runs)
   int trace_x, trace_y;           // instrumented passes only: dump the shading of this pixel
   float* trace_buf;               // 64 floats or NULL
@@ -222,6 +227,57 @@ struct FlattenParams {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+
+// 1.0f / x, correctly rounded (the contract's "IEEE 1/x"), without the compiler's division expansion
+// (v_div_scale x2, v_rcp, five fma, v_div_fmas, v_div_fixup: ~11 instructions where the fragment stage runs
+// three of them per pixel).  v_rcp_f32 is good to 1 ulp; VARIANT picks the refinement, and
+// svr_debug_rcp_sweep (tests/test_parity_gpu.py::test_reciprocal_all_inputs) compares the result with the
+// compiler's 1.0f / x over all 2^32 bit patterns.  Outside the exponent window in which neither the input,
+// the result nor the residuals can be subnormal, and for the few significands the refinement gets wrong
+// (found by that sweep), the division proper runs — a wave-uniform branch that scenes never take.
+//   VARIANT 1: one Newton step   y + y*(1 - x*y)
+//   VARIANT 2: two Newton steps
+//   VARIANT 0: the production form (svr_device.h rcp_ieee)
+template <int VARIANT>
+__device__ __forceinline__ float rcp_refined(float x) {
+  float y = __builtin_amdgcn_rcpf(x);
+  float r = fmaf(-x, y, 1.0f);
+  y = fmaf(r, y, y);
+  if (VARIANT == 2) {
+    r = fmaf(-x, y, 1.0f);
+    y = fmaf(r, y, y);
+  }
+  return y;
+}
+__device__ __forceinline__ bool rcp_fast_ok(float x) {
+  // biased exponent in [32, 222]: |x| in [2^-95, 2^96), so 1/x, x*y and the residual are all normal
+  return ((f2u(x) >> 23) & 0xffu) - 32u <= 190u;
+}
+__device__ __forceinline__ float rcp_ieee(float x) {
+#ifdef SVR_AB_PLAIN_DIV  // A/B builds only (tools/build_variant.sh): the compiler's division everywhere
+  return 1.0f / x;
+#endif
+  if (__builtin_expect(!rcp_fast_ok(x), 0)) return 1.0f / x;
+  return rcp_refined<SVR_RCP_VARIANT>(x);
+}
+
+// three at once (the fragment stage's 1/q at the pixel and at its two quad partners): one window test, one branch
+__device__ __forceinline__ void rcp3_ieee(float a, float b, float c, float& ra, float& rb, float& rc) {
+#ifdef SVR_AB_PLAIN_DIV
+  const bool window = false;
+#else
+  const bool window = rcp_fast_ok(a) && rcp_fast_ok(b) && rcp_fast_ok(c);
+#endif
+  if (__builtin_expect(!window, 0)) {
+    ra = 1.0f / a;
+    rb = 1.0f / b;
+    rc = 1.0f / c;
+    return;
+  }
+  ra = rcp_refined<SVR_RCP_VARIANT>(a);
+  rb = rcp_refined<SVR_RCP_VARIANT>(b);
+  rc = rcp_refined<SVR_RCP_VARIANT>(c);
+}
 
 // post-vertex-shader vertex: gl_Position + 8 varying floats
 struct VOut {
@@ -320,7 +376,7 @@ struct ScreenV {
 // C3: perspective divide + viewport (0,0,W,H,0,1)
 __device__ __forceinline__ ScreenV to_screen(const float* c, float hw, float hh) {
   ScreenV s;
-  s.rw = 1.0f / c[3];
+  s.rw = rcp_ieee(c[3]);
   s.xs = fmaf(c[0] * s.rw, hw, hw);
   s.ys = fmaf(c[1] * s.rw, hh, hh);
   s.zs = c[2] * s.rw;
@@ -399,7 +455,7 @@ __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, cons
     if (!top_left && i == 1) flags |= F_T1;
     if (!top_left && i == 2) flags |= F_T2;
   }
-  float inv_area = 1.0f / (float)(double)area2;
+  float inv_area = rcp_ieee((float)(double)area2);
   if (geom) {
     geom->minx = pminx; geom->miny = pminy; geom->maxx = pmaxx; geom->maxy = pmaxy;
 #pragma unroll
@@ -425,8 +481,8 @@ __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, cons
   rec[4] = pack2(B[1], B[2]);
   rec[5] = pack2(C[0], C[1]);
   {
-    unsigned long long uc = (unsigned long long)__double_as_longlong(C[2]), ub = (unsigned long long)(uintptr_t)tex.base;
-    rec[6] = make_uint4((uint32_t)uc, (uint32_t)(uc >> 32), (uint32_t)ub, (uint32_t)(ub >> 32));
+    unsigned long long uc = (unsigned long long)__double_as_longlong(C[2]);
+    rec[6] = make_uint4((uint32_t)uc, (uint32_t)(uc >> 32), tex.base_off, 0u);
   }
   rec[7] = make_uint4(tex.wh, tex.info, f2u(tex.min_lod), f2u(tex.max_lod));
   // shading half

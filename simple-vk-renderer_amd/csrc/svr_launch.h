@@ -32,5 +32,6 @@ void launch_blit(const void* color, int color_format, uint32_t W, uint32_t H, vo
 void launch_downsample(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh,
                        hipStream_t s);
 void launch_rgba16f_to_rgba8(const void* src, void* dst, uint32_t n_pixels, hipStream_t s);
+void launch_rcp_sweep(int variant, unsigned long long first, unsigned long long count, unsigned long long* out19, hipStream_t s);
 
 }  // namespace svr

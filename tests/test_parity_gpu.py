@@ -399,6 +399,19 @@ def test_full_size_properties_8k_instanced(hip):
     r.close()
 
 
+def test_reciprocal_all_inputs(hip):
+    """The contract's "IEEE 1/x" (perspective divide, 1/area, 1/q per fragment) is computed without the
+    compiler's division expansion: v_rcp_f32 + one Newton step inside an exponent window, the division
+    proper outside it.  All 2^32 bit patterns against the compiler's correctly rounded 1.0f / x."""
+    r = hip.create(16, 16)
+    bad, refined, pats = r.rcp_sweep(0)
+    assert bad == 0, [hex(int(p)) for p in pats]
+    assert refined == 2 * 191 * (1 << 23)   # both signs of the 191 binades of the window took the division-free path
+    bad1, _, pats1 = r.rcp_sweep(1)          # the refinement alone, never the fallback, inside the window
+    assert bad1 == 0, [hex(int(p)) for p in pats1]
+    r.close()
+
+
 def test_errors_on_the_hip_library(hip):
     r = hip.create(16, 16)
     with pytest.raises(pkg.SvrError) as ei:

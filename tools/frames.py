@@ -26,11 +26,12 @@ def main():
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--hist", action="store_true")
     ap.add_argument("--flatten", type=int, default=0, help="SVR_OPT_DEVICE_FLATTEN: 0 auto, 1 device, 2 host")
+    ap.add_argument("--lib", default="", help="another build of libsvr_hip.so (build_ab/...) instead of the product's")
     ap.add_argument("--ab", default="", help="comma list of SVR_OPT_TUNING masks to time interleaved, e.g. 0,1")
     args = ap.parse_args()
     pkg = g.load_package()
-    hip = pkg.load_product_library()
     S, A = pkg.scenes, pkg.abi
+    hip = A.SvrLib(os.path.abspath(args.lib)) if args.lib else pkg.load_product_library()
     sc = S.sponza_like(lod=args.lod, tex_size=args.tex_size)
     r = hip.create(args.width, args.height)
     handles = sc.upload(r)
