@@ -10,10 +10,14 @@ RenderObject list crosses the ABI from host memory every frame exactly as the re
   python bench.py --gpus 1 --steps 300 --warmup 30
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, scene replicated, rank r renders the band of rows [r*H/N,(r+1)*H/N)
-(svr_set_scissor) and the finished bands are exchanged with one RCCL all-gather per frame
-(torch.distributed backend "nccl" == RCCL), two frames in flight so the gather of frame i overlaps
-the rendering of frame i+1; total work is fixed -> "scaling": "strong".
+N > 1: one process per GPU, scene replicated, rank r renders a band of rows (svr_set_scissor) cut so that
+the bands cost alike (dist.BandPlan, re-cut every --rebalance frames from the ranks' tile-row costs), and the
+finished bands are exchanged once per frame over RCCL (torch.distributed backend "nccl"): grouped
+send/recv for unequal bands, one all-gather for equal ones; two frames in flight so the exchange of frame i
+overlaps the rendering of frame i+1; total work is fixed -> "scaling": "strong".
+
+Timing: --warmup untimed frames, then the block of EXACTLY --steps frames (fence + barrier on both sides, max
+over ranks) is repeated >= --blocks times and >= 0.5 s; ms_per_step is the MEDIAN block, p10 / p90 beside it.
 
 Prints ONE JSON line on rank 0.  Extra keys: roofline (tile kernel, HBM bound), cpu_baseline (the
 CPU oracle timed on this host), frames_per_s, rasterized_fragments_per_s, kernel_ms.
@@ -44,25 +48,42 @@ def parse():
     ap.add_argument("--gltf", default="", help="render this .glb/.gltf instead of the synthetic scene (not the BASELINE workload)")
     ap.add_argument("--camera", default="", help="with --gltf: x,y,z,pitch,yaw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--equal-bands", action="store_true", help="N > 1: fixed bands of H/N rows (one all-gather) instead of cost-balanced ones")
+    ap.add_argument("--rebalance", type=int, default=64, help="N > 1: frames between two re-cuts of the row bands (0 = never)")
     ap.add_argument("--gather-fp16", action="store_true", help="N > 1: all-gather the RGBA16F target instead of the swapchain image")
     ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=25, help="repetitions of the timed --steps block (the median block is reported)")
+    ap.add_argument("--profile-tag", default="r02_f", help="profiles/<tag>_traffic.json and <tag>_valu.json of this build are quoted in the line")
     return ap.parse_args()
 
 
 def host_cores():
+    """(threads used for the all-core leg, cores this process may run on, model name from /proc/cpuinfo)."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(n, 16))  # a one-GPU box grants 16 cores; never oversubscribe
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return max(1, n), os.cpu_count() or n, model
 
 
 def cpu_baseline(args, pkg, shaded_per_frame, sc):
-    """The oracle (a scalar C++ port of the path) on this host's cores, same workload, bounded."""
+    """The oracle — a scalar C++ restatement of the path, NOT a binned rasteriser: geometry runs on one thread,
+    rasterisation is split into 16-row bands and every band walks every triangle (oracle/svr_oracle.cpp
+    raster_rows) — on this host's cores, same workload, bounded: one frame on one thread, then --cpu-frames
+    frames on every core this process may use."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import svr_testlib as T
     ora = T.load_oracle()
-    cores = host_cores()
+    cores, hw, model = host_cores()
     S = pkg.scenes
     r = ora.create(args.width, args.height, pkg.abi.COLOR_RGBA16F)
     handles = sc.upload(r)
@@ -70,20 +91,28 @@ def cpu_baseline(args, pkg, shaded_per_frame, sc):
     opaque, transparent = sc.render_objects(handles, instance_transforms=inst)
     pos, pitch, yaw = camera_of(args, S)
     scene = S.scene_data_struct(pos, pitch, yaw, args.width, args.height)
+
+    def frames(n):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r.clear_color((1, 1, 1, 1))
+            r.draw_geometry(scene, opaque, transparent)
+        return (time.perf_counter() - t0) / n
+
     ora.lib.svr_oracle_set_threads(r.h, cores)
-    r.clear_color((1, 1, 1, 1))
-    r.draw_geometry(scene, opaque, transparent)  # warm-up
-    t0 = time.perf_counter()
-    for _ in range(args.cpu_frames):
-        r.clear_color((1, 1, 1, 1))
-        r.draw_geometry(scene, opaque, transparent)
-    dt = (time.perf_counter() - t0) / args.cpu_frames
+    frames(1)  # warm-up
+    dt_all = frames(args.cpu_frames)
+    ora.lib.svr_oracle_set_threads(r.h, 1)
+    dt_one = frames(1)
     r.close()
-    return {"value": shaded_per_frame / dt, "unit": "fragments/s", "cores": cores, "kind": "port",
-            "frames_per_s": 1.0 / dt,
-            "sample": f"{args.cpu_frames} full frames of the same workload ({args.width}x{args.height}) after 1 warm-up, "
-                      f"geometry single-threaded, rasterisation row-band parallel over {cores} threads; "
-                      "fragments counted as the GPU path counts them (each visible pixel once + transparent layers)"}
+    return {"value": shaded_per_frame / dt_all, "unit": "fragments/s", "cores": cores, "kind": "port",
+            "description": "scalar C++ oracle (-O2, no intrinsics, -ffp-contract=off), forward rasteriser, UNBINNED: every 16-row band "
+                           "walks every triangle; geometry single-threaded, rasterisation band-parallel",
+            "frames_per_s": 1.0 / dt_all,
+            "single_thread": {"value": shaded_per_frame / dt_one, "frames_per_s": 1.0 / dt_one, "cores": 1},
+            "hardware_concurrency": hw, "cpu_model": model,
+            "sample": f"{args.cpu_frames} full frames of the same workload ({args.width}x{args.height}) on {cores} threads after 1 warm-up, "
+                      "then 1 frame on 1 thread; fragments counted as the GPU path counts them (each visible pixel once + transparent layers)"}
 
 
 def load_scene(args, pkg):
@@ -135,7 +164,9 @@ def main():
     r.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     # N > 1: the presentable B8G8R8A8 image is what the ranks exchange (4 B/px; --gather-fp16 sends the target)
     present = world > 1 and not args.gather_fp16
-    slots = [D.ShardedFrame(torch, r, rank, world, dev, A.COLOR_RGBA16F, present=present) for _ in range(2)]
+    # cost-balanced row bands (dist.BandPlan): re-cut from the ranks' tile-row costs every --rebalance frames
+    plan = D.BandPlan(H, world, balanced=not args.equal_bands)
+    slots = [D.ShardedFrame(torch, r, rank, world, dev, A.COLOR_RGBA16F, present=present, plan=plan) for _ in range(2)]
     handles = sc.upload(r)
     inst = S.config5_instances() if args.instances == 16 else None
     opaque, transparent = sc.render_objects(handles, instance_transforms=inst)
@@ -144,6 +175,8 @@ def main():
     state = {"i": 0}
 
     def frame():
+        if world > 1 and args.rebalance > 0 and state["i"] % args.rebalance == args.rebalance // 2:
+            plan.rebalance(torch, dist, r, dev)     # a collective, part of the job: timed like everything else
         s = slots[state["i"] & 1]
         state["i"] += 1
         s.begin()                                   # _draw_image of this frame slot + the rank's scissor band
@@ -176,15 +209,30 @@ def main():
         frame()
     fence()
     r.set_option(A.OPT_KERNEL_TIMING, 1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame()
-    fence()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+
+    def block():
+        """EXACTLY --steps frames between two fences (barrier + synchronize on both sides), max over ranks."""
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            frame()
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # SURVEY 8d protocol: the block is repeated (>= 25 times and >= 0.5 s in all, at most 400 times) and the MEDIAN
+    # block is the reported one, with p10 / p90 beside it: one block of a few milliseconds is at the mercy of
+    # whatever else the box does in that instant.  Every rank runs the same number of blocks (rank 0 decides).
+    first = block()
+    n_blocks = int(min(400, max(args.blocks, 0.5 / max(first, 1e-6))))
+    nb = torch.tensor([n_blocks], dtype=torch.int64, device=dev)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dist.broadcast(nb, 0)
+    n_blocks = int(nb.item())
+    times = sorted([first] + [block() for _ in range(n_blocks - 1)])
+    pick = lambda q: times[min(len(times) - 1, max(0, int(round(q * (len(times) - 1)))))]
+    dt, dt_p10, dt_p90 = pick(0.5), pick(0.1), pick(0.9)
     st = r.get_stats()
     r.set_option(A.OPT_KERNEL_TIMING, 0)
 
@@ -195,20 +243,26 @@ def main():
         # (one RGBA8 texel at matched LOD x1.25 for the second mip) + one final store of
         # RGBA16F (8 B) + D32 (4 B) per pixel of this rank's band
         frag_rank = shaded / world
-        tile_bytes = 5.0 * frag_rank + 12.0 * W * slots[0].rows
+        tile_bytes = 5.0 * frag_rank + 12.0 * W * (H / world)
         tile_s = st.tile_ms * 1e-3
         # HBM bytes per launch of that kernel from the PMC counters cannot be collected from inside this
         # process; the committed rocprofv3 --pmc summary of this very command (1 GPU, default size) is quoted
-        traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_h_traffic.json")
-        if world == 1 and not args.gltf and (W, H, args.instances, args.lod, args.tex_size) == (3840, 2160, 1, 1, 1024) and os.path.exists(tpath):
+        traffic, traffic_source, valu = None, None, None
+        default_workload = world == 1 and not args.gltf and (W, H, args.instances, args.lod, args.tex_size) == (3840, 2160, 1, 1, 1024)
+        tpath = os.path.join(ROOT, "profiles", args.profile_tag + "_traffic.json")
+        vpath = os.path.join(ROOT, "profiles", args.profile_tag + "_valu.json")
+        if default_workload and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic, traffic_source = tj["traffic_bytes_per_launch"], "profiles/r01_h_traffic.json: " + tj["correction"]
+            traffic, traffic_source = tj["traffic_bytes_per_launch"], f"profiles/{args.profile_tag}_traffic.json: " + tj["correction"]
+        if default_workload and os.path.exists(vpath):
+            with open(vpath) as f:
+                valu = json.load(f)
         achieved = tile_bytes / tile_s / 1e9 if tile_s > 0 else 0.0
         out = {
             "metric": "shaded fragments/s", "value": shaded * fps, "unit": "fragments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_p10": dt_p10 / args.steps * 1e3, "ms_per_step_p90": dt_p90 / args.steps * 1e3, "timed_blocks": len(times),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": (f"glTF file {os.path.basename(args.gltf)}, {counts_scene['triangles']} triangles, {W}x{H}, RGBA16F+D32,"
@@ -219,17 +273,20 @@ def main():
                        "width": W, "height": H, "triangles": counts_scene["triangles"] * args.instances,
                        "draws": int(len(opaque) + len(transparent)),
                        "textures": f"{len(sc.textures)} images from the file" if args.gltf else f"25 x {args.tex_size}^2 RGBA8 mipmapped",
-                       "parallelism": (f"row bands x{world} + all_gather of the " + ("B8G8R8A8 swapchain image" if present else "RGBA16F target"))
-                                      if world > 1 else "single GPU"},
+                       "parallelism": (f"row bands x{world} ({'equal' if args.equal_bands else 'cost-balanced, rows ' + str(plan.bounds)}) + exchange of the "
+                                       + ("B8G8R8A8 swapchain image" if present else "RGBA16F target")) if world > 1 else "single GPU"},
             "frames_per_s": fps,
             "shaded_fragments_per_frame": shaded, "rasterized_fragments_per_frame": rasterized,
             "rasterized_fragments_per_s": rasterized * fps,
+            "rasterized_per_shaded": rasterized / max(shaded, 1),
             "binned_triangles": binned, "bin_entries": entries,
             "kernel_ms": {"tile": st.tile_ms, "passes": st.timed_passes},
             "roofline": {"bound": "hbm", "kernel": "tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": tile_bytes, "avg_launch_ms": st.tile_ms},
+            # what actually bounds the dominant kernel: VALU issue, from the committed SQ counters of this build
+            "roofline_valu": valu,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, pkg, shaded, sc)

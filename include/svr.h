@@ -291,6 +291,16 @@ int svr_debug_read_bins(SvrContext* ctx, uint32_t* counts, size_t capacity, uint
  * HIP library only. */
 int svr_debug_read_tile_cycles(SvrContext* ctx, uint32_t* cycles, size_t capacity);
 
+/* Load-balancing hook of the multi-GPU form (rank r renders a band of rows): the cost estimate
+ * of the most recently VALIDATED pass per 32-pixel tile row of its scissor — sum over the row's tiles of
+ * 40 + opaque bin entries / 8 + 3/4 transparent bin entries (thousands of cycles, the model the tile kernel's own
+ * split rule is fitted to).  Does not wait for passes in flight: it reports the last one whose completion the
+ * context has already seen (none yet: *n_tile_rows = 0).  *first_row / *n_rows: that pass's scissor rows; tile row t
+ * covers rows first_row + 32 t .. + 31 (clipped to the scissor).  costs may be NULL to query the count.  HIP library:
+ * measured; oracle: 1 per tile row (it has no bins). */
+int svr_get_row_costs(SvrContext* ctx, uint32_t* costs, size_t capacity, uint32_t* n_tile_rows, uint32_t* first_row,
+                      uint32_t* n_rows);
+
 /* Test hook for the arithmetic contract's "IEEE 1/x" (perspective divide, 1/area, 1/q per fragment): compares the
  * reciprocal exactly as the kernels compute it with the compiler's correctly rounded 1.0f / x for the fp32 bit
  * patterns first .. first + count - 1 (all 2^32 in one call is a few milliseconds).  variant 0 = the production

@@ -177,6 +177,7 @@ struct SvrContext {
   std::vector<uint8_t> color8;    // RGBA8
   std::vector<float> depth;
   uint32_t sx = 0, sy = 0, sw = 0, sh = 0;
+  uint32_t pass_sy = 0, pass_sh = 0;  // scissor rows of the last pass (svr_get_row_costs)
   std::vector<std::unique_ptr<Mesh>> meshes;
   std::vector<std::unique_ptr<Image>> images;
   std::vector<Sampler> samplers;
@@ -692,6 +693,8 @@ void raster_rows(SvrContext* ctx, const SvrSceneData* scene, const std::vector<S
 }
 
 int run_pass(SvrContext* ctx, const SvrSceneData* scene, const std::vector<DrawCmd>& cmds) {
+  ctx->pass_sy = ctx->sy;
+  ctx->pass_sh = ctx->sh;
   PassState ps;
   ps.ctx = ctx;
   run_geometry(ps, scene, cmds);
@@ -1247,6 +1250,19 @@ int svr_debug_read_trace(SvrContext* ctx, float out[64]) {
 
 int svr_debug_read_bins(SvrContext*, uint32_t*, size_t, uint32_t*) {
   return fail(SVR_ERR_UNSUPPORTED, "svr_debug_read_bins: the CPU oracle does not bin");
+}
+
+int svr_get_row_costs(SvrContext* ctx, uint32_t* costs, size_t capacity, uint32_t* n_tile_rows, uint32_t* first_row, uint32_t* n_rows) {
+  if (!ctx || !n_tile_rows) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_get_row_costs: null argument");
+  const uint32_t n = (ctx->pass_sh + 31u) / 32u;  // the oracle has no bins to weigh: every tile row costs the same
+  *n_tile_rows = n;
+  if (first_row) *first_row = ctx->pass_sy;
+  if (n_rows) *n_rows = ctx->pass_sh;
+  if (costs) {
+    if (capacity < n) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_get_row_costs: buffer too small");
+    for (uint32_t i = 0; i < n; i++) costs[i] = 1u;
+  }
+  return SVR_OK;
 }
 
 int svr_debug_rcp_sweep(SvrContext*, int, uint64_t, uint64_t, uint64_t*, uint64_t*, uint32_t*) {

@@ -82,7 +82,7 @@ SYMBOLS = ["svr_create", "svr_destroy", "svr_set_stream", "svr_bind_targets", "s
            "svr_read_image_level", "svr_create_sampler", "svr_write_material", "svr_clear_color",
            "svr_draw_background", "svr_copy_to_swapchain", "svr_read_swapchain",
            "svr_set_scissor", "svr_draw_geometry", "svr_draw_colored_triangle", "svr_draw_tex_image",
-           "svr_run_mesh_vert", "svr_set_option", "svr_debug_trace_pixel", "svr_debug_read_trace", "svr_debug_read_bins", "svr_debug_read_tile_cycles", "svr_debug_rcp_sweep", "svr_sync", "svr_read_color", "svr_read_depth", "svr_get_stats",
+           "svr_run_mesh_vert", "svr_set_option", "svr_debug_trace_pixel", "svr_debug_read_trace", "svr_debug_read_bins", "svr_debug_read_tile_cycles", "svr_debug_rcp_sweep", "svr_get_row_costs", "svr_sync", "svr_read_color", "svr_read_depth", "svr_get_stats",
            "svr_last_error", "svr_backend_name"]
 
 
@@ -136,6 +136,8 @@ class SvrLib:
         L.svr_debug_read_trace.argtypes = [P, P]
         L.svr_debug_read_bins.argtypes = [P, P, C.c_size_t, C.POINTER(C.c_uint32)]
         L.svr_debug_read_tile_cycles.argtypes = [P, P, C.c_size_t]
+        if hasattr(L, "svr_get_row_costs"):
+            L.svr_get_row_costs.argtypes = [P, P, C.c_size_t, P, P, P]
         if hasattr(L, "svr_debug_rcp_sweep"):  # tools/ab_libs.py also loads builds that predate it
             L.svr_debug_rcp_sweep.argtypes = [P, C.c_int, C.c_uint64, C.c_uint64, P, P, P]
         L.svr_sync.argtypes = [P]
@@ -319,6 +321,13 @@ class Renderer:
         out = np.zeros((n.value, 4), dtype=np.uint32)
         self.lib.check(self.lib.lib.svr_debug_read_tile_cycles(self.h, out.ctypes.data, out.size))
         return out
+
+    def row_costs(self):
+        """(costs per tile row [uint32], first scissor row, scissor rows) of the last validated pass; empty before any."""
+        n, y0, rows = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        out = np.zeros(512, dtype=np.uint32)
+        self.lib.check(self.lib.lib.svr_get_row_costs(self.h, out.ctypes.data, out.size, C.byref(n), C.byref(y0), C.byref(rows)))
+        return out[:n.value].copy(), y0.value, rows.value
 
     def rcp_sweep(self, variant=0, first=0, count=1 << 32):
         """(mismatches, inputs on the refined path, first mismatching bit patterns) of svr_debug_rcp_sweep."""

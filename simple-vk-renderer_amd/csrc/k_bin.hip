@@ -168,6 +168,18 @@ __global__ __launch_bounds__(256) void offsets_kernel(FrameParams P) {
   base = __shfl(base, 63);
   if (i < n) P.tile_offset[i] = base + inc - v;
   uint32_t cost = i < P.n_tiles ? tile_cost(v, P.tile_count[P.n_tiles + i]) : 0u;  // fill_kernel's split rule needs the sum
+  {  // ... and per tile row, for whoever cuts the frame into row bands of equal cost (svr_get_row_costs): the lanes
+     // of a wave hold consecutive tiles, so every row's lanes are a run; the first lane of each run adds its run's sum
+    const uint32_t row = i < P.n_tiles ? i / P.tiles_x : 0xffffffffu;
+    uint32_t run = cost;
+    for (int off = 1; off < 64; off <<= 1) {  // suffix sums within equal-row runs
+      uint32_t u = __shfl_down(run, off);
+      uint32_t r2 = __shfl_down(row, off);
+      if (lane + (uint32_t)off < 64u && r2 == row) run += u;
+    }
+    const uint32_t prev = __shfl_up(row, 1);
+    if (row != 0xffffffffu && (lane == 0 || prev != row) && run) atomicAdd(&P.row_cost[row], run);
+  }
   for (int off = 32; off > 0; off >>= 1) cost += __shfl_down(cost, off);
   if (lane == 0 && cost) atomicAdd(&P.counters->cost_sum, cost);
   __syncthreads();

@@ -80,14 +80,16 @@ __device__ __forceinline__ void write_draw(const FlattenParams& F, uint32_t slot
   for (int k = 0; k < 16; k++) d.mat[k] = o.transform[k];
 #pragma unroll
   for (int k = 0; k < 4; k++) d.color_factors[k] = ma.cf[k];
+  matmul4(F.viewproj, d.mat, d.mvp);  // C0, once per draw
   d.vtx = me.vtx;
   d.idx = me.idx + o.first_index;
+  d.groups = me.groups;
+  d.first_index = o.first_index;
+  d.pad = 0;
   d.tri_count = o.index_count / 3u;
   d.tri_base = 0;  // prefix_kernel
   d.tex = o.material - 1u;
   d.flags = ((uint32_t)PIPE_MESH << F_KIND_SHIFT) | (ma.pass == SVR_PASS_TRANSPARENT ? F_TRANSPARENT : 0u);
-#pragma unroll
-  for (int k = 0; k < 4; k++) d.pad[k] = 0;
   F.draws[slot] = d;
   F.draw_tris[slot] = d.tri_count;
 }

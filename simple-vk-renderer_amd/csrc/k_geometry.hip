@@ -26,21 +26,78 @@ __device__ __forceinline__ void shade_corner(const DrawDesc& d, uint32_t kind, c
     colored_triangle_mesh_vert(v, d.mat, o);
 }
 
+// Can any fragment of the box [lo, hi] (object space) under clip = mvp * (p, 1) land inside the scissor?  Half-space
+// tests in clip space, no division: every visible point lies inside the clip volume (w > 0 there), where
+// "pixel row >= r" reads y >= (2 r / H - 1) w — linear, so a box whose eight corners all fail one of the tests
+// fails it everywhere.  The scissor planes sit one pixel outside the scissor (snapping and rounding move a
+// vertex by far less).  Lanes 0..7 take one corner each; the verdict is wave-uniform.  NaNs never cull.
+__device__ __forceinline__ bool chunk_can_be_seen(const FrameParams& P, const float* mvp, const float lo[3], const float hi[3], uint32_t lane) {
+  const float px = (lane & 4u) ? hi[0] : lo[0], py = (lane & 2u) ? hi[1] : lo[1], pz = (lane & 1u) ? hi[2] : lo[2];
+  float c[4];
+  matvec4(mvp, px, py, pz, 1.0f, c);
+  const float inv_hw = 2.0f / (float)P.W, inv_hh = 2.0f / (float)P.H;
+  const float x_lo = ((float)P.sx - 1.0f) * inv_hw - 1.0f, x_hi = ((float)(P.sx + P.sw) + 1.0f) * inv_hw - 1.0f;
+  const float y_lo = ((float)P.sy - 1.0f) * inv_hh - 1.0f, y_hi = ((float)(P.sy + P.sh) + 1.0f) * inv_hh - 1.0f;
+  const unsigned long long corners = 0xffull;
+  const bool out_near = c[2] > c[3], out_far = c[2] < 0.0f;
+  const bool out_l = c[0] < x_lo * c[3], out_r = c[0] > x_hi * c[3];
+  const bool out_t = c[1] < y_lo * c[3], out_b = c[1] > y_hi * c[3];
+  const bool gone = (__ballot(out_near) & corners) == corners || (__ballot(out_far) & corners) == corners ||
+                    (__ballot(out_l) & corners) == corners || (__ballot(out_r) & corners) == corners ||
+                    (__ballot(out_t) & corners) == corners || (__ballot(out_b) & corners) == corners;
+  return !gone;
+}
+
 __global__ __launch_bounds__(256, 4) void setup_kernel(FrameParams P) {
-  uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  // the wave's chunk and its draw are wave-uniform: held in SGPRs, so chunk -> draw record is two scalar round
+  // trips (read as per-lane values they were a chain of six vector loads in front of the first index fetch)
+  const uint32_t gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   uint32_t lane = threadIdx.x & 63;
   // device-flattened passes: the grid was sized by the host's upper bound, the real count is on the device
   const uint32_t n_chunks = P.flatten ? P.counters->flat_chunks : P.n_chunks;
-  const bool live = gw < n_chunks;  // wave-uniform; dead waves only attend the barriers
+  bool live = gw < n_chunks;  // wave-uniform; dead waves only attend the barriers
   // a dead wave touches neither the chunk list nor a draw it names: with every object culled the device
   // flatten writes no chunk at all and chunks[0] holds whatever an earlier pass left there (draws[0] is
   // always inside the inputs allocation; nothing read from it is used by a dead wave)
   WaveChunk ch{0u, 0u};
   if (live) ch = P.chunks[gw];
-  const DrawDesc& d = P.draws[ch.draw];
+  ch.draw = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.draw);
+  ch.first_tri = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.first_tri);
+  // the whole 192-byte record at once, through the scalar cache (constant address space: written by an earlier kernel)
+  typedef const __attribute__((address_space(4))) uint32_t* const_words;
+  DrawDesc d;
+  {
+    const_words src = (const_words)(const void*)(P.draws + ch.draw);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&d);
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(DrawDesc) / 4u; i++) dst[i] = src[i];
+  }
+  uint32_t kind = (d.flags >> F_KIND_SHIFT) & 3u;
+  // Whole chunks that cannot reach the scissor — outside the frustum, or (a rank of the multi-GPU path renders a
+  // band of rows) above or below the band — are dropped before a single index is fetched: the box of the chunk's
+  // vertices comes from the mesh's index-group table (svr_upload_mesh).
+  if (live && d.groups && kind != PIPE_COLORED_TRIANGLE) {
+    const uint32_t first = d.first_index + 3u * ch.first_tri, last = first + 3u * min(64u, d.tri_count - ch.first_tri) - 1u;
+    typedef const __attribute__((address_space(4))) float* const_floats;
+    const_floats g0 = (const_floats)(const void*)(d.groups + 6u * (first / GROUP_INDICES));
+    const_floats g1 = (const_floats)(const void*)(d.groups + 6u * (last / GROUP_INDICES));
+    float a[6], b[6], lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {  // both boxes in one round of scalar loads
+      a[k] = g0[k];
+      b[k] = g1[k];
+    }
+    bool boxes_ok = true;  // a box with a non-finite vertex behind it is stored as NaNs: never culled
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      boxes_ok = boxes_ok & (a[k] <= a[3 + k]) & (b[k] <= b[3 + k]);
+      lo[k] = fminf(a[k], b[k]);
+      hi[k] = fmaxf(a[3 + k], b[3 + k]);
+    }
+    if (boxes_ok) live = chunk_can_be_seen(P, d.mvp, lo, hi, lane);
+  }
   uint32_t tri = live ? ch.first_tri + lane : 0xffffffffu;
   uint32_t seq = d.tri_base + tri;
-  uint32_t kind = (d.flags >> F_KIND_SHIFT) & 3u;
   __shared__ uint32_t s_tot[8];
   __shared__ uint4 s_tr[4][64 * 8];  // per wave: one half (8 pieces) of its 64 records, for the transposed store
   uint4 piece[16];
@@ -54,10 +111,7 @@ __global__ __launch_bounds__(256, 4) void setup_kernel(FrameParams P) {
       colored_triangle_vert(1, v1);
       colored_triangle_vert(2, v2);
     } else {
-      float mvp[16];
-      if (kind == PIPE_MESH) {
-        matmul4(P.scene.viewproj, d.mat, mvp);  // sceneData.viewproj * PushConstants.renderMatrix
-      }
+      const float* mvp = d.mvp;  // sceneData.viewproj * PushConstants.renderMatrix, computed once per draw
       uint32_t i0 = d.idx[3 * tri + 0], i1 = d.idx[3 * tri + 1], i2 = d.idx[3 * tri + 2];
       shade_corner(d, kind, mvp, i0, v0);
       shade_corner(d, kind, mvp, i1, v1);
@@ -188,9 +242,7 @@ __global__ __launch_bounds__(64, 4) void clip_kernel(FrameParams P) {
       colored_triangle_vert(1, poly[1]);
       colored_triangle_vert(2, poly[2]);
     } else {
-      float mvp[16];
-      if (kind == PIPE_MESH) matmul4(P.scene.viewproj, d.mat, mvp);
-      for (int k = 0; k < 3; k++) shade_corner(d, kind, mvp, d.idx[3 * it.tri + k], poly[k]);
+      for (int k = 0; k < 3; k++) shade_corner(d, kind, d.mvp, d.idx[3 * it.tri + k], poly[k]);
     }
     int np = clip_polygon(poly, 3);
     if (np < 3) continue;
@@ -259,18 +311,36 @@ void launch_setup(const FrameParams& P, hipStream_t s) {
 // buffer and zero the pass's counters, in one kernel.  A hipMemcpyAsync here is an SDMA packet with
 // ~20 us of signalling between kernels on the critical chain of every pass, a hipMemsetAsync another
 // launch; the staging memory is device-visible, so sixteen bytes per lane over the host link do it.
+// The copy also fills in DrawDesc::mvp = viewproj * mat of the first n_draws records (MESH draws; others get mat):
+// 16-byte piece j + 4 of a record is column j of the product, made from piece j by the thread that would copy it.
 __global__ __launch_bounds__(256) void prologue_kernel(const uint4* host_src, uint4* dst, uint32_t n_copy, uint4* zero,
-                                                       uint32_t n_zero) {
+                                                       uint32_t n_zero, uint32_t n_draws, SvrSceneData scene) {
   const uint32_t stride = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
-  for (uint32_t i = t; i < n_copy; i += stride) dst[i] = host_src[i];
+  constexpr uint32_t PIECES = sizeof(DrawDesc) / 16u;
+  for (uint32_t i = t; i < n_copy; i += stride) {
+    const uint32_t draw = i / PIECES, piece = i % PIECES;
+    uint4 v = host_src[i];
+    if (draw < n_draws && piece >= 4u && piece < 8u) {
+      const uint4 col = host_src[draw * PIECES + piece - 4u];
+      const uint32_t flags = reinterpret_cast<const uint32_t*>(host_src + draw * PIECES)[offsetof(DrawDesc, flags) / 4u];
+      v = col;
+      if (((flags >> F_KIND_SHIFT) & 3u) == PIPE_MESH) {
+        float out[4];
+        matvec4(scene.viewproj, u2f(col.x), u2f(col.y), u2f(col.z), u2f(col.w), out);  // C0
+        v = make_uint4(f2u(out[0]), f2u(out[1]), f2u(out[2]), f2u(out[3]));
+      }
+    }
+    dst[i] = v;
+  }
   for (uint32_t i = t; i < n_zero; i += stride) zero[i] = make_uint4(0, 0, 0, 0);
 }
 
-void launch_prologue(const void* host_src, void* dst, size_t copy_bytes, void* zero, size_t zero_bytes, hipStream_t s) {
+void launch_prologue(const void* host_src, void* dst, size_t copy_bytes, void* zero, size_t zero_bytes, uint32_t n_draws,
+                     const SvrSceneData& scene, hipStream_t s) {
   uint32_t n_copy = (uint32_t)((copy_bytes + 15) / 16), n_zero = (uint32_t)((zero_bytes + 15) / 16);
   uint32_t blocks = std::min<uint32_t>(256u, (std::max(n_copy, n_zero) + 255u) / 256u);
   hipLaunchKernelGGL(prologue_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, s, (const uint4*)host_src, (uint4*)dst, n_copy,
-                     (uint4*)zero, n_zero);
+                     (uint4*)zero, n_zero, n_draws, scene);
 }
 void launch_clip(const FrameParams& P, hipStream_t s) {
   hipLaunchKernelGGL(clip_kernel, dim3(512), dim3(64), 0, s, P);

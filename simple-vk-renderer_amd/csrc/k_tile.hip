@@ -1122,6 +1122,8 @@ __global__ __launch_bounds__(256, SVR_TILE_WAVES) void tile_kernel(FrameParams P
   asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3), "+s"(w4), "+s"(w5), "+s"(w6), "+s"(w7), "+s"(overflow), "+s"(poison), "+s"(n_split));
   const uint4 i0 = make_uint4(w0, w1, w2, w3), i1 = make_uint4(w4, w5, w6, w7);
 
+  if (blockIdx.x == 0 && threadIdx.x < P.tiles_y)  // the pass's cost per tile row, for the host (nobody waits for it)
+    __hip_atomic_store(P.host_row_cost + threadIdx.x, P.row_cost[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // A pass that overflowed a queue is void, and so is everything after it until the host has replayed
   // it (svr_api.hip "the operation log"): the targets stay as they were before the failed pass.
   if (overflow | poison) {

@@ -62,6 +62,7 @@ struct DevBuf {
 struct MeshRes {
   SvrVertex* vtx = nullptr;
   uint32_t* idx = nullptr;
+  float* groups = nullptr;  // float[6] per 192 indices: box of the vertices they name (setup kernel's chunk culling)
   size_t n_vtx = 0, n_idx = 0;
   bool alive = false;
 };
@@ -192,6 +193,9 @@ struct SvrContext {
   void* h_stage[MAX_OPS] = {};  // per log slot
   size_t h_stage_cap[MAX_OPS] = {};
   Counters* h_counters = nullptr;  // pinned, [MAX_OPS]
+  uint32_t* h_row_cost = nullptr;  // pinned, [MAX_OPS][ROW_COST_MAX]: tile-row costs posted by every pass's tile kernel
+  std::vector<uint32_t> row_cost;  // ... of the pass validated last (svr_get_row_costs), with its scissor rows
+  uint32_t row_cost_y0 = 0, row_cost_rows = 0;
 
   // SVR_OPT_KERNEL_TIMING: ring of event quadruples (before setup, after clip, after fill, after tiles)
   static const int TRING = 16;
@@ -394,8 +398,8 @@ int harvest_timing(SvrContext* ctx, int slot) {
   return SVR_OK;
 }
 
-// head of a set's tile buffer: Counters (96 B) + 80 class counters (FrameParams::cls_count), then tile_count
-constexpr size_t TILE_HEAD_BYTES = sizeof(Counters) + 80 * sizeof(uint32_t);
+// head of a set's tile buffer: Counters (96 B) + 80 class counters (FrameParams::cls_count) + ROW_COST_MAX row costs, then tile_count
+constexpr size_t TILE_HEAD_BYTES = sizeof(Counters) + (80 + ROW_COST_MAX) * sizeof(uint32_t);
 static_assert(TILE_HEAD_BYTES % 16 == 0, "tile buffer head layout");
 
 // size the per-pass buffers for P.n_tris and the current capacities, fill the pointers
@@ -415,6 +419,7 @@ int bind_pass_buffers(SvrContext* ctx, FrameParams& P, int set_index) {
   P.big_queue = (uint32_t*)set.bigq.p;
   P.counters = (Counters*)set.tiles.p;
   P.cls_count = (uint32_t*)((char*)set.tiles.p + sizeof(Counters));
+  P.row_cost = P.cls_count + 80;
   P.tile_count = (uint32_t*)((char*)set.tiles.p + TILE_HEAD_BYTES);
   P.tile_offset = P.tile_count + (((size_t)P.n_tiles * 2 + 3) & ~(size_t)3);  // 16-byte aligned
   P.tile_info = (uint4*)(P.tile_offset + (((size_t)P.n_tiles * 2 + 3) & ~(size_t)3));  // 8 words per tile
@@ -463,6 +468,7 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   void* stage = nullptr;
   if (int e = stage_buffer(ctx, op_slot, (flat_op ? n_objects * sizeof(SvrRenderObject) : draw_bytes + chunk_bytes) + 64, &stage)) return e;
   P.host_counters = &ctx->h_counters[op_slot];
+  P.host_row_cost = ctx->h_row_cost + (size_t)op_slot * ROW_COST_MAX;
   P.op_seq = seq;
   if (flat_op) {  // the objects themselves are the input; cull, sort, draw records and chunks happen on the device
     std::memcpy(stage, flat_op->objects.data(), n_objects * sizeof(SvrRenderObject));
@@ -478,7 +484,7 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
       }
   }
   P.draws = (const DrawDesc*)set.inputs.p;
-  P.chunks = (const WaveChunk*)((const char*)set.inputs.p + draw_bytes);  // DrawDesc is 128 B: stays aligned
+  P.chunks = (const WaveChunk*)((const char*)set.inputs.p + draw_bytes);  // DrawDesc is 192 B: stays 16-byte aligned
 
   int ts = -1;
   if (ctx->kernel_timing >= 2) {
@@ -490,7 +496,7 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   }
   // inputs out of the staging buffer + zero the counters, class counters and tile_count (adjacent)
   launch_prologue(stage, set.inputs.p, flat_op ? 0 : draw_bytes + chunk_bytes, P.counters,
-                  TILE_HEAD_BYTES + (size_t)P.n_tiles * 2 * sizeof(uint32_t), g);
+                  TILE_HEAD_BYTES + (size_t)P.n_tiles * 2 * sizeof(uint32_t), flat_op ? 0u : (uint32_t)draws.size(), P.scene, g);
   if (flat_op) {
     FlattenParams F;
     std::memset(&F, 0, sizeof(F));
@@ -655,6 +661,13 @@ int retire_ops(SvrContext* ctx, bool blocking) {
     }
     if (ctx->log[k].P.instrument) note_pass_stats(ctx, ctx->log[k].P, ctx->h_counters[slot]);
     if (ctx->log[k].P.flatten) note_flatten_stats(ctx, ctx->h_counters[slot]);
+    {  // the tile rows' costs of this pass (posted by its tile kernel before anything else)
+      const FrameParams& Pk = ctx->log[k].P;
+      const uint32_t* src = ctx->h_row_cost + (size_t)slot * ROW_COST_MAX;
+      ctx->row_cost.assign(src, src + std::min<uint32_t>(Pk.tiles_y, ROW_COST_MAX));
+      ctx->row_cost_y0 = Pk.sy;
+      ctx->row_cost_rows = Pk.sh;
+    }
     ctx->log.erase(ctx->log.begin(), ctx->log.begin() + (long)k + 1);
   }
   return SVR_OK;
@@ -801,6 +814,8 @@ int upload_flatten_tables(SvrContext* ctx) {
   for (size_t i = 0; i < me.size(); i++) {
     me[i].vtx = ctx->meshes[i].vtx;
     me[i].idx = ctx->meshes[i].idx;
+    me[i].groups = ctx->meshes[i].groups;
+    me[i].pad = 0;
   }
   std::vector<MatEntry> ma(ctx->materials.size());
   for (size_t i = 0; i < ma.size(); i++) {
@@ -906,6 +921,8 @@ int svr_create(const SvrConfig* cfg, SvrContext** out) {
     return bail(r, "hipHostMalloc");
   for (int i = 0; i < SvrContext::MAX_OPS; i++)
     if ((r = hipEventCreate(&ctx->op_done[i])) != hipSuccess || (r = hipEventCreate(&ctx->op_start[i])) != hipSuccess) return bail(r, "hipEventCreate");
+  if ((r = hipHostMalloc((void**)&ctx->h_row_cost, sizeof(uint32_t) * ROW_COST_MAX * SvrContext::MAX_OPS, hipHostMallocDefault)) != hipSuccess)
+    return bail(r, "hipHostMalloc");
   if ((r = hipHostMalloc((void**)&ctx->h_failed_seq, 64, hipHostMallocDefault)) != hipSuccess) return bail(r, "hipHostMalloc");
   *ctx->h_failed_seq = 0;
   if ((r = hipMalloc((void**)&ctx->d_poison, 256)) != hipSuccess) return bail(r, "hipMalloc");
@@ -922,6 +939,7 @@ void svr_destroy(SvrContext* ctx) {
   for (auto& m : ctx->meshes) {
     if (m.vtx) (void)hipFree(m.vtx);
     if (m.idx) (void)hipFree(m.idx);
+    if (m.groups) (void)hipFree(m.groups);
   }
   if (ctx->tex_arena) (void)hipFree(ctx->tex_arena);
   DevBuf* bufs[] = {&ctx->tex_table, &ctx->d_cvt, &ctx->d_trace, &ctx->d_tile_cycles, &ctx->mesh_table, &ctx->mat_table};
@@ -935,6 +953,7 @@ void svr_destroy(SvrContext* ctx) {
   for (int i = 0; i < SvrContext::MAX_OPS; i++)
     if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
   if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+  if (ctx->h_row_cost) (void)hipHostFree(ctx->h_row_cost);
   for (int i = 0; i < SvrContext::MAX_OPS; i++)
     if (ctx->op_done[i]) (void)hipEventDestroy(ctx->op_done[i]);
   for (int i = 0; i < SvrContext::MAX_OPS; i++)
@@ -999,6 +1018,38 @@ int svr_upload_mesh(SvrContext* ctx, const uint32_t* indices, size_t n_indices, 
   }
   if (n_vertices) HIPCHK(hipMemcpy(m.vtx, vertices, n_vertices * sizeof(SvrVertex), hipMemcpyHostToDevice));
   if (n_indices) HIPCHK(hipMemcpy(m.idx, indices, n_indices * 4, hipMemcpyHostToDevice));
+  // Index-group boxes: min / max position of the vertices named by every 192 consecutive indices.  A wave of the
+  // setup kernel handles 64 consecutive triangles of a draw, i.e. at most two such groups, and skips them when
+  // their box cannot reach the scissor.  (The bounds a caller attaches to a RenderObject are the loader's —
+  // src/vk_loader.cpp:366-375, over all vertices of the mesh so far — and only is_visible may trust them.)
+  {
+    const size_t n_groups = (n_indices + GROUP_INDICES - 1) / GROUP_INDICES;
+    std::vector<float> boxes(std::max<size_t>(n_groups, 1) * 6);
+    for (size_t g = 0; g < n_groups; g++) {
+      float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      const size_t end = std::min(n_indices, (g + 1) * GROUP_INDICES);
+      for (size_t i = g * GROUP_INDICES; i < end; i++) {
+        const float* p = vertices[indices[i]].position;
+        for (int k = 0; k < 3; k++) {
+          lo[k] = p[k] < lo[k] ? p[k] : lo[k];
+          hi[k] = p[k] > hi[k] ? p[k] : hi[k];
+          if (!std::isfinite(p[k])) lo[k] = hi[k] = NAN;  // poisons the box for good (comparisons with NaN are false): the kernel never culls on it
+        }
+      }
+      for (int k = 0; k < 3; k++) {
+        boxes[g * 6 + k] = lo[k];
+        boxes[g * 6 + 3 + k] = hi[k];
+      }
+    }
+    hipError_t rg = hipMalloc((void**)&m.groups, boxes.size() * sizeof(float));
+    if (rg == hipSuccess) rg = hipMemcpy(m.groups, boxes.data(), boxes.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (rg != hipSuccess) {
+      (void)hipFree(m.vtx);
+      (void)hipFree(m.idx);
+      if (m.groups) (void)hipFree(m.groups);
+      return fail(SVR_ERR_OUT_OF_MEMORY, std::string("svr_upload_mesh: index-group boxes: ") + hipGetErrorString(rg));
+    }
+  }
   m.n_vtx = n_vertices;
   m.n_idx = n_indices;
   m.alive = true;
@@ -1014,8 +1065,10 @@ int svr_destroy_mesh(SvrContext* ctx, SvrMesh mesh) {
   if (int e = finish_pending(ctx)) return e;
   (void)hipFree(m->vtx);
   (void)hipFree(m->idx);
+  (void)hipFree(m->groups);
   m->vtx = nullptr;
   m->idx = nullptr;
+  m->groups = nullptr;
   m->alive = false;
   return SVR_OK;
 }
@@ -1313,6 +1366,8 @@ int svr_draw_geometry(SvrContext* ctx, const SvrSceneData* scene, const SvrRende
     std::memcpy(d.color_factors, mat.cf, 16);
     d.vtx = m.vtx;
     d.idx = m.idx + o.first_index;
+    d.groups = m.groups;
+    d.first_index = o.first_index;
     d.tri_count = o.index_count / 3;
     d.tex = o.material - 1;
     d.flags = ((uint32_t)PIPE_MESH << F_KIND_SHIFT) | (mat.pass == SVR_PASS_TRANSPARENT ? F_TRANSPARENT : 0u);
@@ -1370,6 +1425,8 @@ int svr_draw_tex_image(SvrContext* ctx, SvrMesh mesh, uint32_t first_index, uint
   std::memcpy(d.mat, render_matrix, 64);
   d.vtx = m->vtx;
   d.idx = m->idx + first_index;
+  d.groups = m->groups;
+  d.first_index = first_index;
   d.tri_count = index_count / 3;
   d.tex = (uint32_t)ctx->materials.size();
   d.flags = (uint32_t)PIPE_TEX_IMAGE << F_KIND_SHIFT;
@@ -1503,6 +1560,20 @@ int svr_debug_read_tile_cycles(SvrContext* ctx, uint32_t* cycles, size_t capacit
     return fail(SVR_ERR_INVALID_ARGUMENT, "svr_debug_read_tile_cycles: SVR_OPT_TILE_CYCLES was off for the last pass or buffer too small");
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(cycles, ctx->last.tile_cycles, 16 * (size_t)ctx->last.n_tiles, hipMemcpyDeviceToHost));
+  return SVR_OK;
+}
+
+int svr_get_row_costs(SvrContext* ctx, uint32_t* costs, size_t capacity, uint32_t* n_tile_rows, uint32_t* first_row, uint32_t* n_rows) {
+  if (!ctx || !n_tile_rows) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_get_row_costs: null argument");
+  if (int e = use_device(ctx)) return e;
+  if (int e = poll_pending(ctx)) return e;  // validates whatever has finished; never waits
+  *n_tile_rows = (uint32_t)ctx->row_cost.size();
+  if (first_row) *first_row = ctx->row_cost_y0;
+  if (n_rows) *n_rows = ctx->row_cost_rows;
+  if (costs) {
+    if (capacity < ctx->row_cost.size()) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_get_row_costs: buffer too small");
+    std::memcpy(costs, ctx->row_cost.data(), ctx->row_cost.size() * sizeof(uint32_t));
+  }
   return SVR_OK;
 }
 

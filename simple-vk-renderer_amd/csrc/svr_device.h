@@ -45,13 +45,16 @@ constexpr uint32_t SPLIT_MAX = 256;            // tiles split per pass at most (
 constexpr uint32_t SPLIT_EXTRA = 4 * SPLIT_MAX;
 constexpr uint32_t SPLIT_MIN_COST = 100;
 constexpr uint32_t SPLIT_TILES_MAX = 4096;     // passes over more tiles run the tile kernel built without the quarter path
+constexpr uint32_t ROW_COST_MAX = 512;        // tile rows of the largest target (16384 / 32)
 constexpr uint32_t TILE_SLOTS = 1024;          // 256 CUs x 4 resident tile workgroups
 __host__ __device__ inline uint32_t tile_cost(uint32_t n_op, uint32_t n_tr) { return 40u + (n_op >> 3) + n_tr - (n_tr >> 2); }
 constexpr uint32_t SPLIT_SORT_MAX = 2048;      // quarters sort in LDS, out of place (k_tile.hip SORT_CAP): larger transparent bins stay whole
 
-// One draw call (RenderObject after cull+sort), 128 bytes.
+// One draw call (RenderObject after cull+sort), 192 bytes.  Read by the setup kernel through scalar loads
+// (the draw is wave-uniform): the whole record arrives in one round trip.
 struct DrawDesc {
   float mat[16];            // MESH: world matrix (push constant); TEX_IMAGE: render_matrix
+  float mvp[16];            // MESH: sceneData.viewproj * mat, once per draw (the C0 fma chain, host or k_flatten); else = mat
   float color_factors[4];   // materialData.color_factors
   const SvrVertex* vtx;     // vertex_buf_address
   const uint32_t* idx;      // index buffer + first_index
@@ -59,9 +62,13 @@ struct DrawDesc {
   uint32_t tri_base;        // sequence number of the draw's first triangle (submission order)
   uint32_t tex;             // TexBinding index
   uint32_t flags;           // kind << F_KIND_SHIFT | F_TRANSPARENT
-  uint32_t pad[4];
+  const float* groups;      // the mesh's index-group boxes (svr_upload_mesh): float[6] = min xyz, max xyz of the vertices
+                            // named by indices [192 g, 192 g + 192); NULL = none (the wave chunks are never skipped)
+  uint32_t first_index;     // the draw's offset in the mesh's index buffer: locates its chunks' groups
+  uint32_t pad;
 };
-static_assert(sizeof(DrawDesc) == 128, "DrawDesc layout");
+static_assert(sizeof(DrawDesc) == 192 && offsetof(DrawDesc, vtx) == 144 && offsetof(DrawDesc, groups) == 176, "DrawDesc layout");
+constexpr uint32_t GROUP_INDICES = 192;  // 64 triangles
 
 // 64 consecutive triangles of one draw: the unit of work of one wave of the setup kernel.
 struct WaveChunk {
@@ -154,6 +161,8 @@ static_assert(sizeof(Counters) == 96, "Counters layout");
 struct MeshEntry {
   const SvrVertex* vtx;
   const uint32_t* idx;
+  const float* groups;
+  uint64_t pad;
 };
 struct MatEntry {
   float cf[4];
@@ -182,6 +191,8 @@ struct FrameParams {
   uint32_t* tile_count;           // [2*n_tiles]: opaque bins then transparent bins
   uint32_t* tile_offset;          // [2*n_tiles]
   uint32_t* cls_count;            // [80] zeroed per pass: [0,33) tiles per weight class, [40,73) placement cursors
+  uint32_t* row_cost;             // [ROW_COST_MAX] zeroed per pass: sum of tile_cost over every tile row (offsets_kernel)
+  uint32_t* host_row_cost;        // pinned: the tile kernel posts row_cost there (svr_get_row_costs: load-balanced row bands)
   Counters* host_counters;        // pinned host copy, written by report_kernel behind the tile kernel
   uint32_t* host_failed_seq;      // pinned: op_seq of the first pass that overflowed since the last recovery (0 = none)
   uint32_t op_seq;                // this pass's number in the context's operation log (never 0)
@@ -421,14 +432,17 @@ __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, cons
   int X2 = __float2int_rn(s2.xs * 256.0f), Y2 = __float2int_rn(s2.ys * 256.0f);
   long long area2 = (long long)(X1 - X0) * (long long)(Y2 - Y0) - (long long)(X2 - X0) * (long long)(Y1 - Y0);
   if (area2 == 0) return false;
-  if (area2 < 0) {
+  // negative orientation: vertices 1 and 2 trade places.  By value (selects): trading the POINTERS made the
+  // three VOuts addressable, i.e. arrays in scratch memory written and re-read through the vector memory path
+  const bool flip = area2 < 0;
+  if (flip) {
     int t;
     t = X1; X1 = X2; X2 = t;
     t = Y1; Y1 = Y2; Y2 = t;
-    const VOut* tv = v1; v1 = v2; v2 = tv;
-    ScreenV ts = s1; s1 = s2; s2 = ts;
     area2 = -area2;
   }
+  const float zs1 = flip ? s2.zs : s1.zs, zs2 = flip ? s1.zs : s2.zs;
+  const float rw1 = flip ? s2.rw : s1.rw, rw2 = flip ? s1.rw : s2.rw;
   int xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
   int ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
   int pminx = (xmin + 127) >> 8, pmaxx = (xmax - 128) >> 8;
@@ -471,7 +485,7 @@ __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, cons
   h.z = key;
   h.w = flags;
   rec[0] = h;
-  rec[1] = make_uint4(f2u(s0.zs), f2u(s1.zs - s0.zs), f2u(s2.zs - s0.zs), f2u(inv_area));
+  rec[1] = make_uint4(f2u(s0.zs), f2u(zs1 - s0.zs), f2u(zs2 - s0.zs), f2u(inv_area));
   auto pack2 = [](double a, double b) {
     unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
     return make_uint4((uint32_t)ua, (uint32_t)(ua >> 32), (uint32_t)ub, (uint32_t)(ub >> 32));
@@ -486,14 +500,15 @@ __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, cons
   }
   rec[7] = make_uint4(tex.wh, tex.info, f2u(tex.min_lod), f2u(tex.max_lod));
   // shading half
-  float rw0 = s0.rw, rw1 = s1.rw, rw2 = s2.rw;
+  float rw0 = s0.rw;
   float sh[32];
   sh[0] = rw0;
   sh[1] = rw1 - rw0;
   sh[2] = rw2 - rw0;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    float p0 = v0->attr[k] * rw0, p1 = v1->attr[k] * rw1, p2 = v2->attr[k] * rw2;
+    const float a1 = flip ? v2->attr[k] : v1->attr[k], a2 = flip ? v1->attr[k] : v2->attr[k];
+    float p0 = v0->attr[k] * rw0, p1 = a1 * rw1, p2 = a2 * rw2;
     sh[3 + k] = p0;
     sh[11 + k] = p1 - p0;
     sh[19 + k] = p2 - p0;

@@ -6,7 +6,9 @@ namespace svr {
 
 // k_geometry.hip
 // copy_bytes / zero_bytes are rounded up to 16: both buffers must be padded accordingly
-void launch_prologue(const void* host_src, void* dst, size_t copy_bytes, void* zero, size_t zero_bytes, hipStream_t s);
+// n_draws: DrawDesc records at the head of the copy whose mvp the kernel fills in (viewproj * mat)
+void launch_prologue(const void* host_src, void* dst, size_t copy_bytes, void* zero, size_t zero_bytes, uint32_t n_draws,
+                     const SvrSceneData& scene, hipStream_t s);
 void launch_setup(const FrameParams& P, hipStream_t s);
 void launch_clip(const FrameParams& P, hipStream_t s);
 void launch_mesh_vert(const SvrVertex* vtx, uint32_t first, uint32_t n, const float* world16,

@@ -1,7 +1,8 @@
-"""The N>1 path on CPU: world_size-2 gloo run of the row-band sharding + in-place all-gather
+"""The N>1 path on CPU: gloo runs (world size 2 and 4) of the row-band sharding + in-place exchange
 (simple-vk-renderer_amd/dist.py), with the CPU oracle standing in for the renderer (test only).
-The gathered frame must equal the single-process full-frame render bit for bit, also when the
-height does not divide by the world size."""
+The gathered frame must equal the single-process full-frame render bit for bit: equal bands (one
+all-gather), a height that does not divide by the world size, cost-balanced unequal bands (batched
+point-to-point), a rank whose band is empty, and the collective that re-cuts the frame."""
 import os
 import socket
 import sys
@@ -23,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, width, height, out_dir, present):
+def _worker(rank, world, port, width, height, out_dir, present, bounds=None, rebalance=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,10 +35,17 @@ def _worker(rank, world, port, width, height, out_dir, present):
         ora = T.load_oracle()
         D = g.load_package().dist
         r, scene, opaque, transparent = T.setup_sponza(ora, width, height, lod=8, tex_size=32)
-        slots = [D.ShardedFrame(torch, r, rank, world, torch.device("cpu"), pkg.abi.COLOR_RGBA16F, bind=False, present=present)
+        plan = D.BandPlan(height, world, balanced=rebalance)
+        if bounds is not None:
+            plan.bounds = list(bounds)
+        slots = [D.ShardedFrame(torch, r, rank, world, torch.device("cpu"), pkg.abi.COLOR_RGBA16F, bind=False, present=present, plan=plan)
                  for _ in range(2)]
         for f in range(3):  # three frames through two slots, asynchronous gathers
             s = slots[f % 2]
+            if rebalance and f == 2:  # the oracle weighs every tile row alike (6 tile rows here: 4 + 2): the re-cut moves the boundary up
+                before = list(plan.bounds)
+                assert plan.rebalance(torch, dist, r, torch.device("cpu")) and plan.updates == 1
+                assert plan.bounds != before and plan.bounds[0] == 0 and plan.bounds[-1] == height and plan.bounds[1] < before[1]
             s.begin()
             r.clear_color((1, 1, 1, 1))
             if s.rows:
@@ -68,6 +76,56 @@ def test_band_allgather_world2(tmp_path, oracle, size, present):
         got = np.load(tmp_path / f"rank{rank}.npy")
         assert got.shape == ref.shape
         assert np.array_equal(got, ref), f"rank {rank}: gathered frame differs from the full-frame render"
+
+
+@pytest.mark.parametrize("world,bounds", [(2, (0, 13, 54)), (4, (0, 7, 7, 40, 54)), (4, (0, 0, 30, 31, 54)), (3, (0, 54, 54, 54))])
+def test_unequal_bands_travel_point_to_point(tmp_path, oracle, world, bounds):
+    """Cost-balanced partitions give unequal bands, possibly empty ones: every rank still ends up with the frame."""
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    w, h = 96, 54
+    mp.spawn(_worker, args=(world, _free_port(), w, h, str(tmp_path), True, bounds), nprocs=world, join=True)
+    full = T.render_sponza(oracle, w, h, lod=8, tex_size=32)
+    ref = full["rgba8"][..., [2, 1, 0, 3]]
+    for rank in range(world):
+        assert np.array_equal(np.load(tmp_path / f"rank{rank}.npy"), ref), f"rank {rank} with bounds {bounds}"
+
+
+def test_rebalance_is_a_collective_that_keeps_the_frame(tmp_path, oracle):
+    """Skewed bands to begin with, re-cut between frames from the ranks' reported row costs (all_reduce of the profile)."""
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    w, h = 64, 135
+    mp.spawn(_worker, args=(2, _free_port(), w, h, str(tmp_path), True, (0, 100, 135), True), nprocs=2, join=True)
+    full = T.render_sponza(oracle, w, h, lod=8, tex_size=32)
+    ref = full["rgba8"][..., [2, 1, 0, 3]]
+    for rank in range(2):
+        assert np.array_equal(np.load(tmp_path / f"rank{rank}.npy"), ref)
+
+
+def test_balanced_bounds_minimise_the_heaviest_band():
+    D = pkg.dist
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        h = int(rng.integers(1, 14))
+        world = int(rng.integers(1, 6))
+        c = rng.integers(0, 50, h) * (rng.random(h) < 0.7)
+        b = D.balanced_bounds(c, world)
+        assert b[0] == 0 and b[-1] == h and len(b) == world + 1 and all(x <= y for x, y in zip(b, b[1:]))
+        got = max(int(c[x:y].sum()) for x, y in zip(b, b[1:]))
+        # brute force over all cuts
+        import itertools
+        best = min(max(int(c[x:y].sum()) for x, y in zip((0,) + cut, cut + (h,)))
+                   for cut in itertools.combinations_with_replacement(range(h + 1), world - 1))
+        assert got == best, (c.tolist(), world, b)
+    # a 4K-like profile: empty top, heavy middle
+    prof = np.concatenate([np.zeros(700, np.int64), np.full(800, 900), np.full(660, 150)])
+    b = D.balanced_bounds(prof, 8)
+    costs = [int(prof[x:y].sum()) for x, y in zip(b, b[1:])]
+    assert max(costs) <= 1.02 * (prof.sum() / 8) + 900
+    # spread(): tile-row costs become per-row costs, clipped to the band
+    rows = D.BandPlan.spread([64, 32], 10, 40, 100)
+    assert rows[:10].sum() == 0 and rows[50:].sum() == 0 and rows[10] == 64 * 1024 // 32 and rows[42] == 32 * 1024 // 8
 
 
 def test_band_rows_partition():

@@ -399,6 +399,31 @@ def test_full_size_properties_8k_instanced(hip):
     r.close()
 
 
+def test_row_costs_are_the_tile_cost_model_per_tile_row(hip):
+    """svr_get_row_costs (what the multi-GPU form balances its row bands with): per tile row of the scissor the
+    sum of 40 + opaque / 8 + 3/4 transparent over the row's tiles, posted by the pass itself."""
+    W, H = 640, 360
+    r, scene, opaque, transparent = T.setup_sponza(hip, W, H, lod=4, tex_size=64)
+    assert r.row_costs()[0].size == 0  # nothing validated yet
+    for (y0, rows) in ((0, H), (50, 201)):
+        r.set_scissor(0, y0, W, rows)
+        r.clear_color((1, 1, 1, 1))
+        r.draw_geometry(scene, opaque, transparent)
+        r.sync()
+        costs, cy0, crows = r.row_costs()
+        op, tr = r.read_bins()
+        tx, ty = (W + 31) // 32, (rows + 31) // 32
+        want = (40 + (op.astype(np.int64) >> 3) + tr - (tr.astype(np.int64) >> 2)).reshape(ty, tx).sum(axis=1)
+        assert (cy0, crows) == (y0, rows) and costs.size == ty
+        assert np.array_equal(costs.astype(np.int64), want)
+    # and the partition made from it is balanced under that model
+    prof = pkg.dist.BandPlan.spread(costs, cy0, crows, H)
+    b = pkg.dist.balanced_bounds(prof, 4)
+    parts = [int(prof[x:y].sum()) for x, y in zip(b, b[1:])]
+    assert max(parts) <= prof.sum() / 4 + prof.max() * 1
+    r.close()
+
+
 def test_reciprocal_all_inputs(hip):
     """The contract's "IEEE 1/x" (perspective divide, 1/area, 1/q per fragment) is computed without the
     compiler's division expansion: v_rcp_f32 + one Newton step inside an exponent window, the division

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--instances", type=int, default=1)
     ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--balanced", action="store_true", help="cut the bands by cost (dist.balanced_bounds over svr_get_row_costs of the full frame) instead of equally")
+    ap.add_argument("--iterations", type=int, default=4, help="--balanced: re-cuts (each from the bands' modelled rows scaled to their measured time)")
+    ap.add_argument("--wall", action="store_true", help="--balanced: scale by the band's wall-clock frame time instead of its GPU time")
     ap.add_argument("--stages", action="store_true", help="also print per-stage kernel times (adds events to the stream)")
     args = ap.parse_args()
     import torch
@@ -45,39 +48,55 @@ def main():
         r.draw_geometry(scene, opaque, transparent)
         r.copy_to_swapchain(swap.data_ptr(), W, H, A.SWAPCHAIN_B8G8R8A8)
 
+    def time_band(y0, rows, n, rk):
+        r.set_scissor(0, y0, W, rows)
+        r.set_option(A.OPT_KERNEL_TIMING, 0)
+        for _ in range(10):
+            frame(y0, rows)
+        r.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.frames):
+            frame(y0, rows)
+        host_ms = (time.perf_counter() - t0) / args.frames * 1e3  # the host's share: it must stay below the GPU's
+        r.sync()
+        ms = (time.perf_counter() - t0) / args.frames * 1e3
+        stage, gpu_ms = "", None
+        if args.stages or args.balanced:
+            r.set_option(A.OPT_KERNEL_TIMING, 2)
+            for _ in range(20):
+                frame(y0, rows)
+            r.sync()
+            st = r.get_stats()
+            gpu_ms = st.geometry_ms + st.binning_ms + st.tile_ms
+            stage = f" (geometry {st.geometry_ms:.3f} binning {st.binning_ms:.3f} tile {st.tile_ms:.3f})"
+        costs, y0c, rowsc = r.row_costs()
+        print(f"  N={n} band {rk}: rows {y0}..{y0 + rows}: {ms:.4f} ms/frame (host enqueue {host_ms:.4f}){stage}", flush=True)
+        return ms, gpu_ms, pkg.dist.BandPlan.spread(costs, y0c, rowsc, H)
+
     base = None
     for n in (1, 2, 4, 8):
         band = (H + n - 1) // n
-        per = []
-        for rk in range(n):
-            y0 = rk * band
-            rows = max(0, min(band, H - y0))
-            r.set_scissor(0, y0, W, rows)
-            r.set_option(A.OPT_KERNEL_TIMING, 0)
-            for _ in range(10):
-                frame(y0, rows)
-            r.sync()
-            t0 = time.perf_counter()
-            for _ in range(args.frames):
-                frame(y0, rows)
-            host_ms = (time.perf_counter() - t0) / args.frames * 1e3  # the host's share: it must stay below the GPU's
-            r.sync()
-            ms = (time.perf_counter() - t0) / args.frames * 1e3
-            stage = ""
-            if args.stages:
-                r.set_option(A.OPT_KERNEL_TIMING, 2)
-                for _ in range(20):
-                    frame(y0, rows)
-                r.sync()
-                st = r.get_stats()
-                stage = f" (geometry {st.geometry_ms:.3f} binning {st.binning_ms:.3f} tile {st.tile_ms:.3f})"
-            per.append(ms)
-            print(f"  N={n} band {rk}: rows {y0}..{y0 + rows}: {ms:.4f} ms/frame (host enqueue {host_ms:.4f}){stage}", flush=True)
-        worst, mean = max(per), float(np.mean(per))
-        if base is None:
-            base = worst
-        print(f"N={n}: slowest band {worst:.4f} ms, mean {mean:.4f} ms -> at most {base / worst:.2f}x of N=1 "
-              f"({base / worst / n * 100:.0f} % efficiency before the gather)", flush=True)
+        plan = pkg.dist.BandPlan(H, n, balanced=args.balanced)
+        for it in range(args.iterations if args.balanced and n > 1 else 1):
+            bounds = plan.bounds
+            per, profile = [], np.zeros(H, dtype=np.int64)
+            for rk in range(n):
+                y0, rows = bounds[rk], bounds[rk + 1] - bounds[rk]
+                if rows == 0:
+                    per.append(0.0)
+                    continue
+                ms, gpu_ms, mine = time_band(y0, rows, n, rk)
+                per.append(ms)
+                # what the ranks' all_reduce would assemble: every band's modelled rows scaled to its measured time
+                profile += pkg.dist.BandPlan.scale_to(mine, ms if args.wall else gpu_ms)
+            worst, mean = max(per), float(np.mean(per))
+            if base is None:
+                base = worst
+            print(f"N={n}{' iteration ' + str(it) + ' rows ' + str(bounds) if args.balanced else ''}: slowest band {worst:.4f} ms, "
+                  f"mean {mean:.4f} ms (slowest / mean {worst / mean:.3f}) -> at most {base / worst:.2f}x of N=1 "
+                  f"({base / worst / n * 100:.0f} % efficiency before the gather)", flush=True)
+            if args.balanced:
+                plan.recut(profile)
 
 
 if __name__ == "__main__":
