@@ -3,6 +3,10 @@
 // library on the GPU box) and as the smallest example of the call sequence init -> load -> draw().
 //
 //   svr_demo --lib <libsvr_*.so> --width 160 --height 90 --frames 2 --dump /tmp/prefix
+//   svr_demo --lib libsvr_hip.so --dist libsvr_dist.so --ranks 2 [--transport shm|rccl] [--bounds 0,13,90] [--rebalance 1]
+//       the sharded frame (include/svr_dist.h): one process per rank (forked before anything touches the GPU;
+//       rccl: rank r on device r; shm: every rank on device 0), every rank dumps the exchanged image as
+//       <prefix>.rank<r>.swapchain — it must be the single-process <prefix>.swapchain
 //
 // Scene: a three-level node hierarchy of cubes (exercises Node::refresh_transform's parent_matrix quirk and
 // MeshNode::Draw's world*top order) with an opaque default material and a Transparent checker one.
@@ -12,6 +16,11 @@
 #include <fstream>
 #include <string>
 
+#include <dlfcn.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include "../../include/svr_dist.h"
 #include "svr_engine.h"
 #include "svr_jpeg.h"
 #include "svr_png.h"
@@ -49,7 +58,8 @@ static void dump(const std::string& path, const T* p, size_t n) {
 }
 
 int main(int argc, char** argv) {
-  std::string lib, prefix, gltf, png;
+  std::string lib, prefix, gltf, png, dist_lib, transport = "shm", bounds_arg;
+  int ranks = 1, rebalance = 0;
   uint32_t w = 160, h = 90;
   int frames = 2, background = 0;
   float cam[5] = {0, 0, 0, 0, 0};  // position, pitch, yaw
@@ -58,6 +68,11 @@ int main(int argc, char** argv) {
     std::string a = argv[i];
     if (a == "--lib") lib = argv[i + 1];
     else if (a == "--gltf") gltf = argv[i + 1];
+    else if (a == "--dist") dist_lib = argv[i + 1];
+    else if (a == "--ranks") ranks = atoi(argv[i + 1]);
+    else if (a == "--transport") transport = argv[i + 1];
+    else if (a == "--bounds") bounds_arg = argv[i + 1];
+    else if (a == "--rebalance") rebalance = atoi(argv[i + 1]);
     else if (a == "--png") png = argv[i + 1];
     else if (a == "--background") background = atoi(argv[i + 1]);
     else if (a == "--swapchain" && sscanf(argv[i + 1], "%ux%u", &sw, &sh) == 2) {}
@@ -97,7 +112,44 @@ int main(int argc, char** argv) {
                     "                [--gltf file.glb|file.gltf --camera x,y,z,pitch,yaw] [--background 0|1] [--swapchain WxH]\n");
     return 2;
   }
+  // the sharded frame: one process per rank, forked before anything touches the GPU; rank 0 makes the id
+  int rank = 0;
+  std::vector<int> id_pipe_r(ranks > 1 ? ranks : 0, -1), id_pipe_w(ranks > 1 ? ranks : 0, -1);
+  if (ranks > 1) {
+    if (dist_lib.empty()) {
+      fprintf(stderr, "--ranks needs --dist <libsvr_dist.so>\n");
+      return 2;
+    }
+    for (int r = 1; r < ranks; r++) {
+      int fd[2];
+      if (pipe(fd) != 0) return 1;
+      id_pipe_r[r] = fd[0];
+      id_pipe_w[r] = fd[1];
+    }
+    std::vector<pid_t> kids;
+    for (int r = 1; r < ranks; r++) {
+      pid_t pid = fork();
+      if (pid < 0) return 1;
+      if (pid == 0) {
+        rank = r;
+        kids.clear();
+        break;
+      }
+      kids.push_back(pid);
+    }
+    if (rank == 0 && !kids.empty()) {  // rank 0 is the parent itself; it reaps the others at the end (below)
+      static std::vector<pid_t> reap;
+      reap = kids;
+      atexit([] {
+        for (pid_t p : reap) {
+          int st = 0;
+          waitpid(p, &st, 0);
+        }
+      });
+    }
+  }
   SvrEngine eng;
+  eng.device = transport == "rccl" ? rank : 0;
   if (!eng.init(lib, w, h)) {
     fprintf(stderr, "init failed: %s\n", eng.error.c_str());
     return 1;
@@ -172,6 +224,101 @@ int main(int argc, char** argv) {
   eng.main_camera.position = {0, 0, 0};
   }
 
+  if (!dist_lib.empty()) {
+    void* dh = dlopen(dist_lib.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!dh) {
+      fprintf(stderr, "dlopen %s: %s\n", dist_lib.c_str(), dlerror());
+      return 1;
+    }
+#define DIST_FN(name) auto name##_ = reinterpret_cast<decltype(&::name)>(dlsym(dh, #name)); if (!name##_) { fprintf(stderr, "missing %s\n", #name); return 1; }
+    DIST_FN(svr_dist_get_unique_id) DIST_FN(svr_dist_create) DIST_FN(svr_dist_destroy) DIST_FN(svr_dist_set_bounds) DIST_FN(svr_dist_get_bounds)
+    DIST_FN(svr_dist_rebalance) DIST_FN(svr_dist_band) DIST_FN(svr_dist_begin_frame) DIST_FN(svr_dist_end_frame) DIST_FN(svr_dist_wait_frame)
+    DIST_FN(svr_dist_read_frame) DIST_FN(svr_dist_last_error)
+#undef DIST_FN
+    const int tr = transport == "rccl" ? SVR_DIST_RCCL : SVR_DIST_SHM;
+    uint8_t id[SVR_DIST_ID_BYTES];
+    if (rank == 0) {
+      if (svr_dist_get_unique_id_(tr, id) != SVR_OK) {
+        fprintf(stderr, "unique id: %s\n", svr_dist_last_error_());
+        return 1;
+      }
+      for (int r = 1; r < ranks; r++)
+        if (write(id_pipe_w[r], id, sizeof(id)) != (ssize_t)sizeof(id)) return 1;
+    } else if (read(id_pipe_r[rank], id, sizeof(id)) != (ssize_t)sizeof(id)) {
+      return 1;
+    }
+    SvrDist* dist = nullptr;
+    if (svr_dist_create_(eng.ctx, tr, id, rank, ranks, w, h, SVR_SWAPCHAIN_B8G8R8A8, &dist) != SVR_OK) {
+      fprintf(stderr, "rank %d: svr_dist_create: %s\n", rank, svr_dist_last_error_());
+      return 1;
+    }
+    if (!bounds_arg.empty()) {
+      std::vector<uint32_t> b;
+      for (size_t p = 0; p < bounds_arg.size();) {
+        b.push_back((uint32_t)strtoul(bounds_arg.c_str() + p, nullptr, 10));
+        size_t c = bounds_arg.find(',', p);
+        p = c == std::string::npos ? bounds_arg.size() : c + 1;
+      }
+      if (svr_dist_set_bounds_(dist, b.data(), b.size()) != SVR_OK) {
+        fprintf(stderr, "rank %d: svr_dist_set_bounds: %s\n", rank, svr_dist_last_error_());
+        return 1;
+      }
+    }
+    int in_flight = 0;
+    std::vector<uint8_t> image((size_t)w * h * 4);
+    for (int f = 0; f < frames; f++) {
+      if (rebalance && f > 0 && f % rebalance == 0) {  // a collective between two frames: every rank, same frame
+        eng.api.svr_sync(eng.ctx);
+        SvrStats st{};
+        eng.api.svr_get_stats(eng.ctx, &st);
+        int changed = 0;
+        if (svr_dist_rebalance_(dist, st.gpu_time_ms, &changed) != SVR_OK) {
+          fprintf(stderr, "rank %d: rebalance: %s\n", rank, svr_dist_last_error_());
+          return 1;
+        }
+        std::vector<uint32_t> b((size_t)ranks + 1);
+        svr_dist_get_bounds_(dist, b.data(), b.size());
+        if (rank == 0) {
+          printf("frame %d: rows", f);
+          for (uint32_t v : b) printf(" %u", v);
+          printf("%s\n", changed ? " (re-cut)" : "");
+        }
+      }
+      if (in_flight == 2) {  // both slots busy: take the older frame first (this is where present was)
+        if (svr_dist_wait_frame_(dist, nullptr) != SVR_OK) return 1;
+        in_flight--;
+      }
+      uint32_t y0 = 0, rows = 0;
+      svr_dist_band_(dist, &y0, &rows);
+      if (svr_dist_begin_frame_(dist) != SVR_OK) {
+        fprintf(stderr, "rank %d: begin_frame: %s\n", rank, svr_dist_last_error_());
+        return 1;
+      }
+      eng.update_scene();
+      if (rows && (!eng.draw_background() || !eng.draw_geometry())) {
+        fprintf(stderr, "rank %d: draw failed: %s\n", rank, eng.error.c_str());
+        return 1;
+      }
+      if (svr_dist_end_frame_(dist) != SVR_OK) {
+        fprintf(stderr, "rank %d: end_frame: %s\n", rank, svr_dist_last_error_());
+        return 1;
+      }
+      in_flight++;
+    }
+    while (in_flight > 1) {
+      if (svr_dist_wait_frame_(dist, nullptr) != SVR_OK) return 1;
+      in_flight--;
+    }
+    if (svr_dist_read_frame_(dist, image.data(), image.size()) != SVR_OK) {
+      fprintf(stderr, "rank %d: read_frame: %s\n", rank, svr_dist_last_error_());
+      return 1;
+    }
+    if (!prefix.empty()) dump(prefix + ".rank" + std::to_string(rank) + ".swapchain", image.data(), image.size());
+    printf("rank %d of %d (%s): %d frames, last one exchanged\n", rank, ranks, transport.c_str(), frames);
+    svr_dist_destroy_(dist);
+    eng.cleanup();
+    return 0;
+  }
   for (int f = 0; f < frames; f++) {
     eng.update_scene();
     if (f == frames - 1 && !prefix.empty()) {

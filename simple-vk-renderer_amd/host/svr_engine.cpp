@@ -108,6 +108,7 @@ bool SvrEngine::init(const std::string& library_path, uint32_t w, uint32_t h) {
   cfg.width = w;
   cfg.height = h;
   cfg.color_format = SVR_COLOR_RGBA16F;  // _draw_image format, src/vk_engine.cpp:749
+  cfg.device = device;
   if (api.svr_create(&cfg, &ctx)) {
     error = api.svr_last_error();
     return false;

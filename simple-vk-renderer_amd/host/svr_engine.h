@@ -111,6 +111,7 @@ struct SvrEngine {
   SvrApi api;
   SvrContext* ctx = nullptr;
   uint32_t width = 1700, height = 900;  // _window_extent, src/vk_engine.h:219
+  int device = 0;                        // SvrConfig.device: the rank's GPU in the sharded form (svr_dist.h)
   int frame_number = 0;
   EngineStats stats;
   DrawContext main_draw_context;

@@ -112,3 +112,50 @@ def test_cpp_host_on_the_hip_library(tmp_path, hip, oracle):
     demo = run_demo(hip.path, str(tmp_path / "demo"))
     assert "backend hip-gfx950" in demo["log"]
     check(demo, oracle, oracle)  # HIP frame from C++ == oracle frame from Python
+
+
+# ---------------------------------------------------------------- the sharded frame for a C++ host (include/svr_dist.h)
+DIST_LIB = os.path.join(g.PKG_DIR, "csrc", "libsvr_dist.so")
+
+
+def test_dist_library_exports_its_header():
+    """libsvr_dist.so (built by __graft_entry__.build) exports every symbol include/svr_dist.h declares and sits on
+    libsvr_hip.so + librccl; running it needs GPUs (below)."""
+    import re
+    g.build()
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(g.ROOT, "include", "svr_dist.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(svr_dist_[a-z0-9_]+)\s*\(", text)))
+    assert len(declared) >= 12
+    out = subprocess.run(["nm", "-D", "--defined-only", DIST_LIB], check=True, stdout=subprocess.PIPE, text=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    assert not set(declared) - exported, set(declared) - exported
+    ldd = subprocess.run(["ldd", DIST_LIB], stdout=subprocess.PIPE, text=True).stdout
+    assert "libsvr_hip.so" in ldd and "librccl" in ldd and "oracle" not in ldd
+
+
+def run_dist_demo(hip_path, prefix, ranks, transport, extra=()):
+    subprocess.run(["make", "-s"], cwd=HOST_DIR, check=True)
+    p = subprocess.run([os.path.join(HOST_DIR, "svr_demo"), "--lib", hip_path, "--dist", DIST_LIB, "--ranks", str(ranks), "--transport", transport,
+                        "--width", str(W), "--height", str(H), "--frames", "5", "--dump", prefix, *extra],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout
+    return p.stdout, [np.fromfile(f"{prefix}.rank{r}.swapchain", dtype=np.uint8).reshape(H, W, 4) for r in range(ranks)]
+
+
+@pytest.mark.gpu
+def test_cpp_sharded_frame(tmp_path, hip):
+    """svr_demo --ranks N: N processes on the one GPU of the test box, bands exchanged through the shared-memory
+    transport; every rank's exchanged image must be the single-process swapchain image, for equal bands, explicit
+    unequal bands with an empty one, and after a cost re-cut.  RCCL itself is exercised with one rank (it refuses two
+    ranks on one device): communicator, all-gather and destroy on hardware."""
+    single = str(tmp_path / "single")
+    run_demo(hip.path, single)
+    want = np.fromfile(single + ".swapchain", dtype=np.uint8).reshape(H, W, 4)
+    for ranks, extra in ((2, ()), (3, ("--bounds", "0,13,13,90")), (2, ("--bounds", "0,70,90", "--rebalance", "2"))):
+        log, images = run_dist_demo(hip.path, str(tmp_path / f"d{ranks}{len(extra)}"), ranks, "shm", extra)
+        for r, img in enumerate(images):
+            assert np.array_equal(img, want), f"{ranks} ranks {extra}: rank {r}\n{log}"
+        if "--rebalance" in extra:
+            assert "re-cut" in log, log
+    log, images = run_dist_demo(hip.path, str(tmp_path / "rccl1"), 1, "rccl")
+    assert np.array_equal(images[0], want), log
