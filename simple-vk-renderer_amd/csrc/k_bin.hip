@@ -138,6 +138,8 @@ __global__ __launch_bounds__(256) void count_kernel(FrameParams P, uint32_t rest
 // reserves the span of its 64 bins with one atomic on the running total (wave prefix sum inside).
 // The same kernel builds the histogram of tile weight classes for the tile kernel's launch order:
 // class = bit length of (opaque + 2*transparent) entries.
+// (Classes by estimated cost — tile_cost, two per octave, so that the curtain tiles lead the launch instead of
+// sharing a class with merely triangle-rich opaque tiles — measured slower: 0.2007 vs 0.1959 ms at 4K.)
 __device__ __forceinline__ uint32_t weight_class(const FrameParams& P, uint32_t t) {
   return 32u - (uint32_t)__clz(P.tile_count[t] + 2u * P.tile_count[P.n_tiles + t]);
 }
