@@ -762,6 +762,11 @@ __device__ __forceinline__ void rank_sort_big(const FrameParams& P, unsigned cha
 // the next power of two >= n words (fill_kernel reserved it; global memory is coherent inside a workgroup's CU).
 // out: where the sorted record indices go — the bin itself, or (quarters of a split tile, n <= RANK_SORT_MAX) the
 // tile's words of the sort arena, which all four quarters fill with the same values.
+// WIDE: bins of 1025 .. 2048 entries keep all eight elements of a thread in registers (rank_sort<5..8>) instead of
+// going through rank_sort_big.  For the kernel built with the quarter path (passes of up to 4096 tiles: 1080p, the
+// row bands of a multi-GPU run) whose frame time IS its deepest curtain tile: 2.5 % of the 1080p frame; in the
+// whole-tile kernel the same choice costs the phases every tile runs more (registers) than it returns.
+template <bool WIDE>
 __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned long long* s, uint32_t* marks, uint32_t bin_base, uint32_t n,
                                                 uint32_t* out) {
   if (n <= SORT_CAP) {
@@ -772,14 +777,18 @@ __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned l
       case 2: rank_sort<2>(P, lds, bin_base, n, out); break;
       case 3: rank_sort<3>(P, lds, bin_base, n, out); break;
       case 4: rank_sort<4>(P, lds, bin_base, n, out); break;
-#ifdef SVR_AB_RANK8  // A/B builds only: eight elements per thread in registers (the register peak of the kernel)
-      case 5: rank_sort<5>(P, lds, bin_base, n, out); break;
-      case 6: rank_sort<6>(P, lds, bin_base, n, out); break;
-      case 7: rank_sort<7>(P, lds, bin_base, n, out); break;
-      default: rank_sort<8>(P, lds, bin_base, n, out); break;
-#else
-      default: rank_sort_big(P, lds, marks, bin_base, n, out); break;
-#endif
+      default:
+        if (WIDE) {
+          switch ((n + 255u) >> 8) {
+            case 5: rank_sort<5>(P, lds, bin_base, n, out); break;
+            case 6: rank_sort<6>(P, lds, bin_base, n, out); break;
+            case 7: rank_sort<7>(P, lds, bin_base, n, out); break;
+            default: rank_sort<8>(P, lds, bin_base, n, out); break;
+          }
+        } else {
+          rank_sort_big(P, lds, marks, bin_base, n, out);
+        }
+        break;
     }
     __threadfence_block();
     __syncthreads();
@@ -1027,12 +1036,12 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(s_c + LDS_C_OFF);
     if (QUARTER) {  // n_tr <= SORT_CAP: sorted in LDS, written out of place
       uint32_t* shared_list = reinterpret_cast<uint32_t*>(P.sort_arena + sort_base);
-      sort_bin_by_key(P, scratch, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, shared_list);
+      sort_bin_by_key<SPLIT>(P, scratch, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, shared_list);
       order = shared_list;
     } else if (n_tr <= SORT_CAP) {
-      sort_bin_by_key(P, scratch, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, P.bins + tbase);
+      sort_bin_by_key<SPLIT>(P, scratch, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, P.bins + tbase);
     } else {
-      sort_bin_by_key(P, P.sort_arena + sort_base, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, P.bins + tbase);  // rare: a bin too large for LDS
+      sort_bin_by_key<SPLIT>(P, P.sort_arena + sort_base, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, P.bins + tbase);  // rare: a bin too large for LDS
     }
 #pragma unroll
     for (int k = 0; k < 4; k++)  // colour loadOp LOAD for what neither the opaque pass nor a clear has written
