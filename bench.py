@@ -63,6 +63,13 @@ def host_cores():
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
+    try:  # a container's CPU quota (cgroup v2 cpu.max "quota period"): threads beyond it only take turns
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    n = min(n, 64)  # the oracle's band-parallel rasteriser stops scaling long before (its geometry half is one thread)
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:

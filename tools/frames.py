@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--hist", action="store_true")
     ap.add_argument("--flatten", type=int, default=0, help="SVR_OPT_DEVICE_FLATTEN: 0 auto, 1 device, 2 host")
     ap.add_argument("--timing", type=int, default=2, help="SVR_OPT_KERNEL_TIMING during the frames (2 = events around every stage, perturbs the pipeline; 0 for traces)")
+    ap.add_argument("--tuning", type=int, default=0, help="SVR_OPT_TUNING mask (2 = stages serialised)")
     ap.add_argument("--lib", default="", help="another build of libsvr_hip.so (build_ab/...) instead of the product's")
     ap.add_argument("--ab", default="", help="comma list of SVR_OPT_TUNING masks to time interleaved, e.g. 0,1")
     args = ap.parse_args()
@@ -41,6 +42,7 @@ def main():
     pos, pitch, yaw = S.config5_camera() if args.instances == 16 else S.config3_camera()
     scene = S.scene_data_struct(pos, pitch, yaw, args.width, args.height)
     r.set_option(A.OPT_DEVICE_FLATTEN, args.flatten)
+    r.set_option(A.OPT_TUNING, args.tuning)
     r.set_option(A.OPT_KERNEL_TIMING, args.timing)
     for _ in range(3):
         r.clear_color((1, 1, 1, 1))
