@@ -182,15 +182,28 @@ def _read_container(path):
 def _accessor(doc, buffers, index):
     """-> float32 [count, ncomp] (integers converted as the C++ loader / fastgltf do) and the raw ints."""
     acc = doc["accessors"][index]
-    bv = doc["bufferViews"][acc["bufferView"]]
     dt = np.dtype(_COMP[acc["componentType"]])
     nc = _NCOMP[acc["type"]]
-    start = bv.get("byteOffset", 0) + acc.get("byteOffset", 0)
-    stride = bv.get("byteStride", 0) or dt.itemsize * nc
-    buf = np.frombuffer(buffers[bv["buffer"]], dtype=np.uint8)
     count = acc["count"]
-    rows = np.lib.stride_tricks.as_strided(buf[start:], shape=(count, dt.itemsize * nc), strides=(stride, 1))
-    vals = np.ascontiguousarray(rows).view(dt).reshape(count, nc)
+
+    def view_bytes(bv_index, extra=0):
+        bv = doc["bufferViews"][bv_index]
+        return np.frombuffer(buffers[bv["buffer"]], dtype=np.uint8)[bv.get("byteOffset", 0) + extra:], bv
+
+    if "bufferView" in acc:
+        buf, bv = view_bytes(acc["bufferView"], acc.get("byteOffset", 0))
+        stride = bv.get("byteStride", 0) or dt.itemsize * nc
+        rows = np.lib.stride_tricks.as_strided(buf, shape=(count, dt.itemsize * nc), strides=(stride, 1))
+        vals = np.ascontiguousarray(rows).view(dt).reshape(count, nc).copy()
+    else:
+        vals = np.zeros((count, nc), dtype=dt)
+    if "sparse" in acc:  # glTF 2.0 3.6.2.3: `count` elements replaced (the base is zeros without a bufferView)
+        sp = acc["sparse"]
+        ibuf, _ = view_bytes(sp["indices"]["bufferView"], sp["indices"].get("byteOffset", 0))
+        idt = np.dtype(_COMP[sp["indices"]["componentType"]])
+        idx = np.ascontiguousarray(ibuf[:sp["count"] * idt.itemsize]).view(idt).astype(np.int64)
+        vbuf, _ = view_bytes(sp["values"]["bufferView"], sp["values"].get("byteOffset", 0))
+        vals[idx] = np.ascontiguousarray(vbuf[:sp["count"] * dt.itemsize * nc]).view(dt).reshape(sp["count"], nc)
     if dt == np.float32:
         return vals, vals
     f = vals.astype(np.float32)

@@ -136,20 +136,51 @@ struct AccessorReader {
   bool init(const Asset& a, long long index, std::string* err) {
     const Value& acc = a.json["accessors"][(size_t)index];
     if (!acc.is_object()) return fail(err, "accessor index out of range");
-    if (acc.has("sparse")) return fail(err, "sparse accessors are not supported");
     ctype = acc["componentType"].int_or(0);
     csize = component_size(ctype);
     ncomp = type_components(acc["type"].string_or(""));
     count = (size_t)acc["count"].int_or(0);
     normalized = acc["normalized"].kind == Value::Bool && acc["normalized"].b;
     if (!csize || !ncomp) return fail(err, "unsupported accessor type");
-    if (!acc.has("bufferView")) return fail(err, "accessor without a bufferView");
-    if (!buffer_view(a, acc["bufferView"].int_or(-1), view)) return fail(err, "bad bufferView");
-    offset = (size_t)acc["byteOffset"].int_or(0);
-    stride = view.stride ? view.stride : (size_t)(csize * ncomp);
-    if (count && offset + (count - 1) * stride + (size_t)(csize * ncomp) > view.length) return fail(err, "accessor runs past its bufferView");
+    const size_t elem = (size_t)(csize * ncomp);
+    const bool sparse = acc.has("sparse");
+    if (!acc.has("bufferView") && !sparse) return fail(err, "accessor without a bufferView");
+    if (acc.has("bufferView")) {
+      if (!buffer_view(a, acc["bufferView"].int_or(-1), view)) return fail(err, "bad bufferView");
+      offset = (size_t)acc["byteOffset"].int_or(0);
+      stride = view.stride ? view.stride : elem;
+      if (count && offset + (count - 1) * stride + elem > view.length) return fail(err, "accessor runs past its bufferView");
+    }
+    if (!sparse) return true;
+    // Sparse accessor (glTF 2.0 section 3.6.2.3; fastgltf's iterateAccessor, src/vk_loader.cpp:311-357, reads them):
+    // the base elements — zeros without a bufferView — with `count` of them replaced; made dense here once.
+    dense.assign(count * elem, 0);
+    if (acc.has("bufferView"))
+      for (size_t i = 0; i < count; i++) std::memcpy(dense.data() + i * elem, view.data + offset + i * stride, elem);
+    const Value& sp = acc["sparse"];
+    const size_t n = (size_t)sp["count"].int_or(0);
+    const Value& si = sp["indices"];
+    const Value& sv = sp["values"];
+    View iv, vv;
+    if (!buffer_view(a, si["bufferView"].int_or(-1), iv) || !buffer_view(a, sv["bufferView"].int_or(-1), vv)) return fail(err, "bad sparse bufferView");
+    const long long ict = si["componentType"].int_or(0);
+    const size_t isz = (size_t)component_size(ict), ioff = (size_t)si["byteOffset"].int_or(0), voff = (size_t)sv["byteOffset"].int_or(0);
+    if (ict != 5121 && ict != 5123 && ict != 5125) return fail(err, "bad sparse index type");
+    if (ioff + n * isz > iv.length || voff + n * elem > vv.length) return fail(err, "sparse data runs past its bufferView");
+    for (size_t k = 0; k < n; k++) {
+      uint32_t idx = 0;
+      std::memcpy(&idx, iv.data + ioff + k * isz, isz);  // little-endian u8 / u16 / u32
+      if (idx >= count) return fail(err, "sparse index out of range");
+      std::memcpy(dense.data() + (size_t)idx * elem, vv.data + voff + k * elem, elem);
+    }
+    view.data = dense.data();
+    view.length = dense.size();
+    view.stride = 0;
+    offset = 0;
+    stride = elem;
     return true;
   }
+  std::vector<uint8_t> dense;  // a sparse accessor's elements, materialised
   static bool fail(std::string* err, const char* m) {
     if (err) *err = m;
     return false;

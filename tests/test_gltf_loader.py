@@ -234,12 +234,22 @@ def build_handwritten(tmp_path):
     a_idx16 = acc(view(cube.indices.astype(np.uint16).tobytes()), 5123, 36, "SCALAR")
     # primitive B: positions only (shifted), uint8 indices, no material
     posb = (pos + np.float32([2.5, 0.25, 0])).astype(np.float32)
-    b_pos = acc(view(posb.tobytes()), 5126, 24, "VEC3")
+    # ... as a SPARSE accessor: three vertices of the base data are junk and come from the sparse values (u16 indices)
+    base_b = posb.copy()
+    base_b[[3, 7, 20]] = np.float32([[9, 9, 9], [-7, 0, 3], [1e3, 1e3, 1e3]])
+    b_pos = acc(view(base_b.tobytes()), 5126, 24, "VEC3")
+    accs[b_pos]["sparse"] = {"count": 3,
+                             "indices": {"bufferView": view(np.uint16([3, 7, 20]).tobytes()), "componentType": 5123},
+                             "values": {"bufferView": view(posb[[3, 7, 20]].tobytes())}}
     b_idx8 = acc(view(cube.indices.astype(np.uint8).tobytes()), 5121, 36, "SCALAR")
     # primitive C (second mesh): no indices at all (GenerateMeshIndices), VEC3 float colours
     tri = np.float32([[-1, 0, 0], [1, 0, 0], [0, 1.5, 0], [-1, 0, 1], [0, 1.5, 1], [1, 0, 1]])
     c_pos = acc(view(tri.tobytes()), 5126, 6, "VEC3")
-    c_col = acc(view(np.float32([[1, 0.5, 0.25]] * 6).tobytes()), 5126, 6, "VEC3")
+    # colours: a sparse accessor WITHOUT a bufferView (zeros underneath), every element supplied (u8 indices)
+    accs.append({"componentType": 5126, "count": 6, "type": "VEC3",
+                 "sparse": {"count": 6, "indices": {"bufferView": view(np.uint8([0, 1, 2, 3, 4, 5]).tobytes()), "componentType": 5121},
+                            "values": {"bufferView": view(np.float32([[1, 0.5, 0.25]] * 6).tobytes())}}})
+    c_col = len(accs) - 1
     image_views = [view(png) for png, _ in imgs] + [view(b"not an image at all")]
     doc = {
         "asset": {"version": "2.0"},
