@@ -200,6 +200,11 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def note(msg):  # progress on stderr (rank 0): a multi-rank run that stalls says where
+        if rank == 0 and world > 1:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"{world} ranks up, scene resident")
     # one instrumented frame: fragment counts (not timed)
     r.set_option(A.OPT_COUNT_FRAGMENTS, 1)
     frame()
@@ -212,9 +217,11 @@ def main():
     shaded, rasterized, binned, entries = [int(v) for v in counts.tolist()]
     r.set_option(A.OPT_COUNT_FRAGMENTS, 0)
 
+    note(f"instrumented frame done: {shaded} shaded fragments")
     for _ in range(args.warmup):
         frame()
     fence()
+    note(f"warm-up done, rows {plan.bounds}")
     r.set_option(A.OPT_KERNEL_TIMING, 1)
 
     def block():
@@ -237,7 +244,9 @@ def main():
     if world > 1:
         dist.broadcast(nb, 0)
     n_blocks = int(nb.item())
+    note(f"first block {first * 1e3:.2f} ms, {n_blocks} blocks to go")
     times = sorted([first] + [block() for _ in range(n_blocks - 1)])
+    note(f"timed blocks done, rows {plan.bounds}")
     pick = lambda q: times[min(len(times) - 1, max(0, int(round(q * (len(times) - 1)))))]
     dt, dt_p10, dt_p90 = pick(0.5), pick(0.1), pick(0.9)
     st = r.get_stats()

@@ -191,6 +191,20 @@ class ShardedFrame:
             n = self.band * self.W * 4
             h = dist.all_gather_into_tensor(self.flat, self.flat[self.rank * n:(self.rank + 1) * n], async_op=async_op)
             return h if async_op else None
+        if self.image_t.is_cuda and dist.get_backend() == "gloo":
+            # rehearsals on a one-GPU box (SVR_BENCH_REHEARSE): gloo moves device tensors only through its collectives,
+            # not point to point — the bands travel padded to the tallest one (a list all_gather) and are copied into place
+            tallest = max(b - a for a, b in zip(self.bounds, self.bounds[1:]))
+            pad = self.torch.zeros((tallest, self.W, 4), dtype=self.image_t.dtype, device=self.image_t.device)
+            rows = self.bounds[self.rank + 1] - self.bounds[self.rank]
+            pad[:rows].copy_(self.image_t[self.bounds[self.rank]:self.bounds[self.rank + 1]])
+            parts = [self.torch.empty_like(pad) for _ in range(self.world)]
+            dist.all_gather(parts, pad)
+            for peer in range(self.world):
+                n = self.bounds[peer + 1] - self.bounds[peer]
+                if peer != self.rank and n:
+                    self.image_t[self.bounds[peer]:self.bounds[peer + 1]].copy_(parts[peer][:n])
+            return None
         ops = []
         mine = self.image_t[self.bounds[self.rank]:self.bounds[self.rank + 1]]
         for peer in range(self.world):
