@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--camera", default="", help="with --gltf: x,y,z,pitch,yaw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--equal-bands", action="store_true", help="N > 1: fixed bands of H/N rows (one all-gather) instead of cost-balanced ones")
+    ap.add_argument("--min-gain", type=float, default=0.2, help="N > 1: a cost-balanced cut replaces the equal bands only if it shortens the heaviest band by this fraction (unequal bands cost the host a batch of send/recv per frame instead of one all-gather)")
     ap.add_argument("--rebalance", type=int, default=64, help="N > 1: frames between two re-cuts of the row bands (0 = never)")
     ap.add_argument("--gather-fp16", action="store_true", help="N > 1: all-gather the RGBA16F target instead of the swapchain image")
     ap.add_argument("--cpu-frames", type=int, default=3)
@@ -172,7 +173,7 @@ def main():
     # N > 1: the presentable B8G8R8A8 image is what the ranks exchange (4 B/px; --gather-fp16 sends the target)
     present = world > 1 and not args.gather_fp16
     # cost-balanced row bands (dist.BandPlan): re-cut from the ranks' tile-row costs every --rebalance frames
-    plan = D.BandPlan(H, world, balanced=not args.equal_bands)
+    plan = D.BandPlan(H, world, balanced=not args.equal_bands, min_gain=args.min_gain)
     slots = [D.ShardedFrame(torch, r, rank, world, dev, A.COLOR_RGBA16F, present=present, plan=plan) for _ in range(2)]
     handles = sc.upload(r)
     inst = S.config5_instances() if args.instances == 16 else None

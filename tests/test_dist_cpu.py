@@ -35,7 +35,7 @@ def _worker(rank, world, port, width, height, out_dir, present, bounds=None, reb
         ora = T.load_oracle()
         D = g.load_package().dist
         r, scene, opaque, transparent = T.setup_sponza(ora, width, height, lod=8, tex_size=32)
-        plan = D.BandPlan(height, world, balanced=rebalance)
+        plan = D.BandPlan(height, world, balanced=rebalance, min_gain=0.0)
         if bounds is not None:
             plan.bounds = list(bounds)
         slots = [D.ShardedFrame(torch, r, rank, world, torch.device("cpu"), pkg.abi.COLOR_RGBA16F, bind=False, present=present, plan=plan)
@@ -123,6 +123,12 @@ def test_balanced_bounds_minimise_the_heaviest_band():
     b = D.balanced_bounds(prof, 8)
     costs = [int(prof[x:y].sum()) for x, y in zip(b, b[1:])]
     assert max(costs) <= 1.02 * (prof.sum() / 8) + 900
+    # the plan keeps the equal bands (one all-gather) unless the balanced cut shortens the heaviest band enough
+    mild = np.concatenate([np.full(1080, 100), np.full(1080, 115)]).astype(np.int64)
+    plan = D.BandPlan(2160, 8, min_gain=0.2)
+    assert not plan.recut(mild) and plan.bounds == D.equal_bounds(2160, 8)
+    assert plan.recut(prof) and plan.bounds != D.equal_bounds(2160, 8) and plan.bounds == D.balanced_bounds(prof, 8)
+    assert plan.recut(mild) and plan.bounds == D.equal_bounds(2160, 8)   # and goes back when the frame evens out
     # spread(): tile-row costs become per-row costs, clipped to the band
     rows = D.BandPlan.spread([64, 32], 10, 40, 100)
     assert rows[:10].sum() == 0 and rows[50:].sum() == 0 and rows[10] == 64 * 1024 // 32 and rows[42] == 32 * 1024 // 8

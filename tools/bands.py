@@ -76,7 +76,7 @@ def main():
     base = None
     for n in (1, 2, 4, 8):
         band = (H + n - 1) // n
-        plan = pkg.dist.BandPlan(H, n, balanced=args.balanced)
+        plan = pkg.dist.BandPlan(H, n, balanced=args.balanced, min_gain=0.0)
         for it in range(args.iterations if args.balanced and n > 1 else 1):
             bounds = plan.bounds
             per, profile = [], np.zeros(H, dtype=np.int64)
