@@ -424,6 +424,42 @@ def test_row_costs_are_the_tile_cost_model_per_tile_row(hip):
     r.close()
 
 
+def test_texel_arena_grows_and_reuses(hip, oracle):
+    """Every image of a context lives in one arena (texel = arena + 32-bit offset): growing it moves the texels of the
+    images already there (their offsets stay), destroying an image leaves a hole the next one of its size takes, and a
+    frame rendered afterwards still samples the right texels."""
+    rng = np.random.default_rng(99)
+    r = hip.create(64, 64)
+    small = [rng.integers(0, 256, (32, 32, 4), dtype=np.uint8) for _ in range(3)]
+    h_small = [r.create_image(t, mipmapped=True) for t in small]
+    big = rng.integers(0, 256, (2048, 2048, 4), dtype=np.uint8)
+    h_big = [r.create_image(big, mipmapped=True) for _ in range(5)]            # 5 x 22 MiB: past the first 64 MiB
+    for t, h in zip(small, h_small):
+        assert np.array_equal(r.read_image_level(h, 0), t)                      # survived the moves
+    assert np.array_equal(r.read_image_level(h_big[0], 0), big) and np.array_equal(r.read_image_level(h_big[4], 0), big)
+    lvl3 = r.read_image_level(h_big[2], 3)
+    r.destroy_image(h_big[1])
+    again = r.create_image(big[::-1].copy(), mipmapped=True)                    # takes the hole
+    assert np.array_equal(r.read_image_level(again, 0), big[::-1]) and np.array_equal(r.read_image_level(h_big[2], 3), lvl3)
+    assert np.array_equal(r.read_image_level(h_big[0], 0), big)
+    r.close()
+    # and a frame over textures created around a growth step is the oracle's
+    def frame(lib):
+        rr = lib.create(96, 64)
+        pad = [rr.create_image(big, mipmapped=True) for _ in range(2)]
+        tex = rr.create_image(small[0], mipmapped=True)
+        pad.append(rr.create_image(big, mipmapped=True))                       # grows the HIP arena after `tex` was placed
+        mesh = rr.upload_mesh(SC.QUAD_IDX, SC.clip_quad(-1, -1, 1, 1, 0.5))
+        smp = rr.create_sampler(**S.SAMPLER_TRILINEAR)
+        mat = rr.write_material(A.PASS_MAIN_COLOR, (1, 1, 1, 1), tex, smp)
+        rr.clear_color((0, 0, 0, 1))
+        rr.draw_geometry(SC.identity_scene(), SC.objs([SC.render_object(mesh, mat, 0, 6)]))
+        out = rr.read_color().copy()
+        rr.close()
+        return out
+    assert np.array_equal(frame(hip), frame(oracle))
+
+
 def test_reciprocal_all_inputs(hip):
     """The contract's "IEEE 1/x" (perspective divide, 1/area, 1/q per fragment) is computed without the
     compiler's division expansion: v_rcp_f32 + one Newton step inside an exponent window, the division
