@@ -66,7 +66,8 @@ def write_glb(scene, path, node_locals=None, image_format="PNG"):
     """scene: scenes.Scene.  Nodes are written flat, each with its world matrix as `matrix`, unless
     node_locals gives [(mesh or None, 4x4 local, [children])] to write a hierarchy verbatim.
     image_format "JPEG" stores the textures lossily (Pillow, RGB, quality 90, 4:2:0): for exercising the
-    loader's JPEG path, not for bit comparisons with the directly uploaded scene."""
+    loader's JPEG path, not for bit comparisons with the directly uploaded scene.  "TGA" (run-length) and
+    "BMP" store them losslessly in formats only stb_image's breadth makes loadable."""
     b = _Bin()
     meshes = []
     for mesh in scene.meshes:
@@ -87,10 +88,16 @@ def write_glb(scene, path, node_locals=None, image_format="PNG"):
         import io
         from PIL import Image
         buf = io.BytesIO()
-        Image.fromarray(np.ascontiguousarray(t[..., :3])).save(buf, "JPEG", quality=90)
+        if image_format == "JPEG":
+            Image.fromarray(np.ascontiguousarray(t[..., :3])).save(buf, "JPEG", quality=90)
+        elif image_format == "TGA":
+            Image.fromarray(np.ascontiguousarray(t), "RGBA").save(buf, "TGA", compression="tga_rle")
+        else:
+            Image.fromarray(np.ascontiguousarray(t), "RGBA").save(buf, image_format)
         return buf.getvalue()
 
-    mime = "image/png" if image_format == "PNG" else "image/jpeg"
+    # glTF names only PNG and JPEG; the reference passes whatever bytes it finds to stb_image, mimeType unread
+    mime = {"PNG": "image/png", "JPEG": "image/jpeg"}.get(image_format, "application/octet-stream")
     images = [{"name": f"image{i}", "mimeType": mime, "bufferView": b.view(encode(t))} for i, t in enumerate(scene.textures)]
     samplers = []
     for s in scene.samplers:
@@ -216,7 +223,7 @@ def _accessor(doc, buffers, index):
 
 
 def _host_decode(data):
-    """PNG / JPEG bytes -> RGBA8 through host/svr_demo --png (svr_png.h / svr_jpeg.h), or None if the host
+    """Image file bytes (any format stb_image takes) -> RGBA8 through host/svr_demo --png (svr_image.h), or None if the host
     harness is not built or refuses the file (the caller then falls back to Pillow)."""
     import os
     import subprocess

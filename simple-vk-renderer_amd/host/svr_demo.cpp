@@ -22,8 +22,7 @@
 
 #include "../../include/svr_dist.h"
 #include "svr_engine.h"
-#include "svr_jpeg.h"
-#include "svr_png.h"
+#include "svr_image.h"
 
 using namespace svrhost;
 
@@ -86,24 +85,16 @@ int main(int argc, char** argv) {
     std::ifstream f(png, std::ios::binary);
     std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     std::string err;
-    uint32_t iw = 0, ih = 0;
-    std::vector<uint8_t> rgba;
-    if (bytes.size() >= 2 && bytes[0] == 0xff && bytes[1] == 0xd8) {
-      svrjpeg::Image img;
-      if (!svrjpeg::decode(bytes.data(), bytes.size(), img, &err)) {
-        fprintf(stderr, "png: %s\n", err.c_str());
-        return 1;
-      }
-      iw = img.w; ih = img.h; rgba.swap(img.rgba);
-    } else {
-      svrpng::Image img;
-      if (!svrpng::decode(bytes.data(), bytes.size(), img, &err)) {
-        fprintf(stderr, "png: %s\n", err.c_str());
-        return 1;
-      }
-      iw = img.w; ih = img.h; rgba.swap(img.rgba);
+    svrimg::Image img;
+    const char* format = "";
+    if (!svrimg::decode(bytes.data(), bytes.size(), img, &err, &format)) {
+      fprintf(stderr, "%s: %s\n", format, err.c_str());
+      return 1;
     }
-    printf("png %u %u\n", iw, ih);
+    uint32_t iw = img.w, ih = img.h;
+    std::vector<uint8_t> rgba;
+    rgba.swap(img.rgba);
+    printf("png %u %u %s\n", iw, ih, format);
     if (!prefix.empty()) dump(prefix + ".rgba", rgba.data(), rgba.size());
     return 0;
   }

@@ -1,7 +1,7 @@
 // svr_gltf.cpp — load_gltf_meshes: a .glb / .gltf file -> LoadedScene uploaded through the engine.
 //
 // Follows the reference loader step for step (src/vk_loader.cpp:162-437) with its own container/JSON/
-// accessor reader in place of fastgltf and svr_png.h / svr_jpeg.h in place of stb_image:
+// accessor reader in place of fastgltf and svr_image.h (svr_png.h, svr_jpeg.h and the minor formats) in place of stb_image:
 //   samplers   :197-211  mag/min filter default NEAREST when absent, mipmap mode from the min filter
 //                        (default LINEAR), minLod 0, maxLod = VK_LOD_CLAMP_NONE, address modes REPEAT
 //   images     :218-231  decode to RGBA8, create_image(..., mipmapped); failure -> error checkerboard
@@ -17,8 +17,7 @@
 
 #include "svr_engine.h"
 #include "svr_json.h"
-#include "svr_jpeg.h"
-#include "svr_png.h"
+#include "svr_image.h"
 
 namespace svrhost {
 
@@ -297,13 +296,8 @@ SvrImage load_image(SvrEngine* engine, const Asset& a, const Value& image) {
     return 0;
   }
   std::string err;
-  if (n >= 2 && p[0] == 0xff && p[1] == 0xd8) {  // JPEG
-    svrjpeg::Image jimg;
-    if (!svrjpeg::decode(p, n, jimg, &err)) return 0;
-    return engine->create_image(jimg.rgba.data(), jimg.w, jimg.h, true);
-  }
-  svrpng::Image img;
-  if (!svrpng::decode(p, n, img, &err)) return 0;
+  svrimg::Image img;  // PNG, BMP, GIF, PSD, PIC, JPEG, PNM, HDR, TGA: whatever stbi_load_from_memory takes
+  if (!svrimg::decode(p, n, img, &err)) return 0;
   return engine->create_image(img.rgba.data(), img.w, img.h, true);  // MIPMAP_ENABLED, :24
 }
 

@@ -3,8 +3,10 @@
 The expected pixels come from the reference's vendored stb_image (thirdparty/stb_image/stb_image.h,
 the decoder behind load_image, src/vk_loader.cpp:81-160) compiled and run in this container by
 `make -C oracle ref` (oracle/_ref/stb_decode).  The files themselves are made here: hand-assembled PNGs
-(every colour type / bit depth / filter / interlace) and Pillow-encoded PNGs and JPEGs (baseline and
-progressive, 4:4:4 / 4:2:2 / 4:2:0 / greyscale, odd extents, restart markers).  Run where
+(every colour type / bit depth / filter / interlace), Pillow-encoded PNGs and JPEGs (baseline and
+progressive, 4:4:4 / 4:2:2 / 4:2:0 / greyscale, odd extents, restart markers), and the minor formats
+stb_image also takes (BMP, TGA, PGM/PPM, GIF, PSD, Softimage PIC, Radiance HDR:
+tests/golden/minor_image_cases.py).  Run where
 /root/reference exists; the .npz travels with the repository, the reference does not.
 
     python tests/make_golden_images.py
@@ -22,6 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gltf_loader as TL  # noqa: E402  (the hand-assembled PNGs)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import minor_image_cases  # noqa: E402  (BMP, TGA, PNM, GIF, PSD, PIC, HDR)
 
 STB = os.path.join(ROOT, "oracle", "_ref", "stb_decode")
 
@@ -77,15 +81,21 @@ def main():
     rng = np.random.default_rng(11)
     cases = [(f"png_hand_{k}", png) for k, (png, _exp) in enumerate(TL.make_test_images(np.random.default_rng(7)))]
     cases += pillow_cases(rng)
+    cases += minor_image_cases.all_cases(np.random.default_rng(23))
     names, blobs, dims, pixels = [], [], [], []
+    refused = minor_image_cases.refused_cases(np.random.default_rng(29))
     with tempfile.TemporaryDirectory() as tmp:
-        for name, data in cases:
+        def reference(name, data):
             src, dst = os.path.join(tmp, name), os.path.join(tmp, name + ".bin")
             with open(src, "wb") as f:
                 f.write(data)
             r = subprocess.run([STB, src, dst], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-            if r.returncode != 0:
-                print(f"{name}: the reference's decoder refuses it ({r.stdout.strip()}): skipped")
+            return (r.returncode == 0), r.stdout.strip(), dst
+
+        for name, data in cases:
+            ok, said, dst = reference(name, data)
+            if not ok:
+                print(f"{name}: the reference's decoder refuses it ({said}): skipped")
                 continue
             raw = np.fromfile(dst, dtype=np.uint8)
             w, h = np.frombuffer(raw[:8].tobytes(), dtype=np.uint32)
@@ -93,11 +103,18 @@ def main():
             blobs.append(np.frombuffer(data, dtype=np.uint8))
             dims.append((int(w), int(h)))
             pixels.append(raw[8:])
+        for name, data in refused:
+            ok, said, _ = reference(name, data)
+            if ok:
+                raise SystemExit(f"{name}: meant to be refused, but the reference's decoder takes it")
+            print(f"{name}: refused as intended ({said})")
     out = os.path.join(ROOT, "tests", "golden", "images.npz")
     np.savez_compressed(out, names=np.array(names), dims=np.array(dims, dtype=np.uint32),
                         file_sizes=np.array([b.size for b in blobs], dtype=np.uint32), files=np.concatenate(blobs),
-                        pixels=np.concatenate(pixels))
-    print(f"{len(names)} images -> {out} ({os.path.getsize(out)} bytes)")
+                        pixels=np.concatenate(pixels), refused_names=np.array([n for n, _ in refused]),
+                        refused_sizes=np.array([len(d) for _, d in refused], dtype=np.uint32),
+                        refused_files=np.frombuffer(b"".join(d for _, d in refused), dtype=np.uint8))
+    print(f"{len(names)} images + {len(refused)} refused files -> {out} ({os.path.getsize(out)} bytes)")
 
 
 if __name__ == "__main__":
