@@ -513,12 +513,36 @@ __device__ __forceinline__ void flush_fragments(const FrameParams& P, typename C
   qn = rest;
 }
 
+// The thread's index in the workgroup for the phases behind visibility, from the wave's number (an SGPR: wv) and
+// the lane's: three instructions where they are wanted.  threadIdx.x itself arrives in v0 and cannot be made again;
+// read in these phases it stays live from the top of the kernel through the fragment stage, and the allocator answers by
+// spilling it — the kernel then carries a scratch frame, which costs every dispatch ~2.5 us (tools/gapbench.hip).
+// volatile asm: copies must not be merged back into one long-lived value.
+__device__ __forceinline__ uint32_t tid_of(uint32_t wv) {
+  uint32_t lane;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+  return (wv << 6) | lane;
+}
+
+// Workgroup-wide OR of a per-thread flag: every wave posts its own vote, one barrier, everybody reads the four.
+// (HIP's __syncthreads_or / _and go through the device library's workgroup reduction, which forms a three-
+// dimensional thread index out of v0 — and so keeps v0 alive, spilled, across the whole kernel.)  SLOT: votes that
+// may follow each other without a barrier in between must use different slots.
+template <int SLOT>
+__device__ __forceinline__ bool block_any(bool v, uint32_t wv) {
+  __shared__ __attribute__((aligned(16))) uint32_t votes[2][4];
+  votes[SLOT][wv] = __any(v) ? 1u : 0u;  // 64 lanes, one word, one value
+  __syncthreads();
+  const uint4 all = *reinterpret_cast<const uint4*>(votes[SLOT]);
+  return (all.x | all.y | all.z | all.w) != 0u;
+}
+
 template <int FMT, bool INSTR>
 __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, const uint32_t* order,
                                                      uint32_t n, int tx0, int ty0, int row0, uint32_t lrpw, const uint32_t* s_z,
                                                      typename Codec<FMT>::enc_t* col, uint2* q, unsigned long long* mask, float4* s_src,
-                                                     uint32_t& n_raster, uint32_t& n_shaded) {
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+                                                     uint32_t& n_raster, uint32_t& n_shaded, const uint32_t wv) {
+  const uint32_t tid = tid_of(wv), lane = tid & 63u, wave = wv;
   const unsigned long long below = (1ull << lane) - 1ull;
   const int rpw = 1 << lrpw;  // rows per wave: 8, or 2 in a quarter
   const int by0 = ty0 + row0 + rpw * (int)wave, by1 = by0 + rpw - 1;  // this wave's rows
@@ -527,7 +551,9 @@ __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4
     uint32_t cnt = min((uint32_t)BATCH, n - b0);
     __syncthreads();
     {  // a thread's two pieces: both indices first, then both records — two round trips per batch, not four
-      const uint32_t t0 = threadIdx.x >> 3, pc = threadIdx.x & 7u;
+      // (the thread index afresh per batch: the staging addresses made from it are otherwise hoisted out of the loop,
+      // where they are the values that get spilled)
+      const uint32_t st = tid_of(wv), t0 = st >> 3, pc = st & 7u;
       uint32_t ri0 = 0, ri1 = 0;
       if (t0 < cnt) ri0 = order[b0 + t0];
       if (t0 + 32u < cnt) ri1 = order[b0 + 32u + t0];
@@ -535,11 +561,11 @@ __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4
       if (t0 < cnt) r0 = reinterpret_cast<const uint4*>(P.recs + ri0)[pc];
       if (t0 + 32u < cnt) r1 = reinterpret_cast<const uint4*>(P.recs + ri1)[pc];
       if (t0 < cnt) {
-        s_cov[threadIdx.x] = r0;
+        s_cov[st] = r0;
         if (pc == 0) s_idx[t0] = ri0;
       }
       if (t0 + 32u < cnt) {
-        s_cov[threadIdx.x + 256u] = r1;
+        s_cov[st + 256u] = r1;
         if (pc == 0) s_idx[t0 + 32u] = ri1;
       }
     }
@@ -636,18 +662,19 @@ __device__ __forceinline__ void count_ranks(const KeyT* s, uint32_t n, const Key
 }
 
 template <uint32_t K>
-__device__ __forceinline__ void rank_sort(const FrameParams& P, unsigned char* lds, uint32_t bin_base, uint32_t n, uint32_t* out) {
+__device__ __forceinline__ void rank_sort(const FrameParams& P, unsigned char* lds, uint32_t bin_base, uint32_t n, uint32_t* out, const uint32_t wv) {
+  const uint32_t tid = tid_of(wv);
   uint32_t* k32 = reinterpret_cast<uint32_t*>(lds);         // [n] keys
   uint32_t* claim = k32 + SORT_CAP;                          // [n] element that owns each rank
   uint32_t ri[K], key[K], rank[K];
 #pragma unroll
   for (uint32_t k = 0; k < K; k++) {
-    uint32_t i = threadIdx.x + 256u * k;
+    uint32_t i = tid + 256u * k;
     ri[k] = i < n ? P.bins[bin_base + i] : 0u;
   }
 #pragma unroll
   for (uint32_t k = 0; k < K; k++) {
-    uint32_t i = threadIdx.x + 256u * k;
+    uint32_t i = tid + 256u * k;
     key[k] = i < n ? P.recs[ri[k]].key : 0u;
     if (i < n) k32[i] = key[k];
   }
@@ -655,22 +682,22 @@ __device__ __forceinline__ void rank_sort(const FrameParams& P, unsigned char* l
   count_ranks<K, uint32_t>(k32, n, key, rank);
 #pragma unroll
   for (uint32_t k = 0; k < K; k++) {
-    uint32_t i = threadIdx.x + 256u * k;
+    uint32_t i = tid + 256u * k;
     if (i < n) claim[rank[k]] = i;
   }
   __syncthreads();
   bool lost = false;
 #pragma unroll
   for (uint32_t k = 0; k < K; k++) {
-    uint32_t i = threadIdx.x + 256u * k;
+    uint32_t i = tid + 256u * k;
     lost = lost || (i < n && claim[rank[k]] != i);
   }
-  if (__syncthreads_or(lost)) {  // equal keys in the bin: rank (key, record index) instead
+  if (block_any<0>(lost, wv)) {  // equal keys in the bin: rank (key, record index) instead
     unsigned long long* k64 = reinterpret_cast<unsigned long long*>(lds);
     unsigned long long wide[K];
 #pragma unroll
     for (uint32_t k = 0; k < K; k++) {
-      uint32_t i = threadIdx.x + 256u * k;
+      uint32_t i = tid + 256u * k;
       wide[k] = ((unsigned long long)key[k] << 32) | ri[k];
       if (i < n) k64[i] = wide[k];
     }
@@ -679,21 +706,22 @@ __device__ __forceinline__ void rank_sort(const FrameParams& P, unsigned char* l
   }
 #pragma unroll
   for (uint32_t k = 0; k < K; k++)
-    if (threadIdx.x + 256u * k < n) out[rank[k]] = ri[k];
+    if (tid + 256u * k < n) out[rank[k]] = ri[k];
 }
 
 template <uint32_t K>
-__device__ __forceinline__ void rank_pass(const uint32_t* k32, const uint32_t* r32, uint32_t* marks, uint32_t base, uint32_t n, uint32_t* out) {
+__device__ __forceinline__ void rank_pass(const uint32_t* k32, const uint32_t* r32, uint32_t* marks, uint32_t base, uint32_t n, uint32_t* out, const uint32_t wv) {
+  const uint32_t tid = tid_of(wv);
   uint32_t mine[K], rank[K];
 #pragma unroll
   for (uint32_t k = 0; k < K; k++) {
-    uint32_t i = base + threadIdx.x + 256u * k;
+    uint32_t i = base + tid + 256u * k;
     mine[k] = i < n ? k32[i] : 0xffffffffu;
   }
   count_ranks<K, uint32_t>(k32, n, mine, rank);
 #pragma unroll
   for (uint32_t k = 0; k < K; k++) {
-    uint32_t i = base + threadIdx.x + 256u * k;
+    uint32_t i = base + tid + 256u * k;
     if (i < n) {
       out[rank[k]] = r32[i];
       marks[rank[k]] = 1u;
@@ -709,24 +737,25 @@ __device__ __forceinline__ void rank_pass(const uint32_t* k32, const uint32_t* r
 // sorts this bin (the quarters of a split tile) reads it in the same order.
 // marks: [SORT_CAP] words of LDS outside the scratch block (the record staging buffer, idle during the sort).
 __device__ __forceinline__ void rank_sort_big(const FrameParams& P, unsigned char* lds, uint32_t* marks, uint32_t bin_base, uint32_t n,
-                                              uint32_t* out) {
+                                              uint32_t* out, const uint32_t wv) {
+  const uint32_t tid = tid_of(wv);
   uint32_t* k32 = reinterpret_cast<uint32_t*>(lds);  // [n] keys
   uint32_t* r32 = k32 + SORT_CAP;                     // [n] record indices
   {  // all record indices, then all keys: two round trips for the whole bin
     uint32_t ri[8], key[8];
 #pragma unroll
     for (uint32_t k = 0; k < 8; k++) {
-      uint32_t i = threadIdx.x + 256u * k;
+      uint32_t i = tid + 256u * k;
       ri[k] = i < n ? P.bins[bin_base + i] : 0u;
     }
 #pragma unroll
     for (uint32_t k = 0; k < 8; k++) {
-      uint32_t i = threadIdx.x + 256u * k;
+      uint32_t i = tid + 256u * k;
       key[k] = i < n ? P.recs[ri[k]].key : 0u;
     }
 #pragma unroll
     for (uint32_t k = 0; k < 8; k++) {
-      uint32_t i = threadIdx.x + 256u * k;
+      uint32_t i = tid + 256u * k;
       if (i < n) {
         k32[i] = key[k];
         r32[i] = ri[k];
@@ -735,18 +764,18 @@ __device__ __forceinline__ void rank_sort_big(const FrameParams& P, unsigned cha
     }
   }
   __syncthreads();  // every entry of the bin has been read: sorting in place is safe
-  rank_pass<4>(k32, r32, marks, 0u, n, out);
+  rank_pass<4>(k32, r32, marks, 0u, n, out, wv);
   switch ((n - 1024u + 255u) >> 8) {  // the elements from 1024 on: as many per thread as there are
-    case 1: rank_pass<1>(k32, r32, marks, 1024u, n, out); break;
-    case 2: rank_pass<2>(k32, r32, marks, 1024u, n, out); break;
-    case 3: rank_pass<3>(k32, r32, marks, 1024u, n, out); break;
-    default: rank_pass<4>(k32, r32, marks, 1024u, n, out); break;
+    case 1: rank_pass<1>(k32, r32, marks, 1024u, n, out, wv); break;
+    case 2: rank_pass<2>(k32, r32, marks, 1024u, n, out, wv); break;
+    case 3: rank_pass<3>(k32, r32, marks, 1024u, n, out, wv); break;
+    default: rank_pass<4>(k32, r32, marks, 1024u, n, out, wv); break;
   }
   __syncthreads();
   bool hole = false;
-  for (uint32_t r = threadIdx.x; r < n; r += 256u) hole = hole || marks[r] == 0u;
-  if (__syncthreads_or(hole)) {  // equal keys: rank (key, position)
-    for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+  for (uint32_t r = tid; r < n; r += 256u) hole = hole || marks[r] == 0u;
+  if (block_any<0>(hole, wv)) {  // equal keys: rank (key, position)
+    for (uint32_t i = tid; i < n; i += 256u) {
       const uint32_t m = k32[i];
       uint32_t rank = 0;
       for (uint32_t j = 0; j < n; j++) {
@@ -768,25 +797,26 @@ __device__ __forceinline__ void rank_sort_big(const FrameParams& P, unsigned cha
 // whole-tile kernel the same choice costs the phases every tile runs more (registers) than it returns.
 template <bool WIDE>
 __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned long long* s, uint32_t* marks, uint32_t bin_base, uint32_t n,
-                                                uint32_t* out) {
+                                                uint32_t* out, const uint32_t wv) {
+  const uint32_t tid = tid_of(wv);
   if (n <= SORT_CAP) {
     unsigned char* lds = reinterpret_cast<unsigned char*>(s);
     switch ((n + 255u) >> 8) {
       case 0:
-      case 1: rank_sort<1>(P, lds, bin_base, n, out); break;
-      case 2: rank_sort<2>(P, lds, bin_base, n, out); break;
-      case 3: rank_sort<3>(P, lds, bin_base, n, out); break;
-      case 4: rank_sort<4>(P, lds, bin_base, n, out); break;
+      case 1: rank_sort<1>(P, lds, bin_base, n, out, wv); break;
+      case 2: rank_sort<2>(P, lds, bin_base, n, out, wv); break;
+      case 3: rank_sort<3>(P, lds, bin_base, n, out, wv); break;
+      case 4: rank_sort<4>(P, lds, bin_base, n, out, wv); break;
       default:
         if (WIDE) {
           switch ((n + 255u) >> 8) {
-            case 5: rank_sort<5>(P, lds, bin_base, n, out); break;
-            case 6: rank_sort<6>(P, lds, bin_base, n, out); break;
-            case 7: rank_sort<7>(P, lds, bin_base, n, out); break;
-            default: rank_sort<8>(P, lds, bin_base, n, out); break;
+            case 5: rank_sort<5>(P, lds, bin_base, n, out, wv); break;
+            case 6: rank_sort<6>(P, lds, bin_base, n, out, wv); break;
+            case 7: rank_sort<7>(P, lds, bin_base, n, out, wv); break;
+            default: rank_sort<8>(P, lds, bin_base, n, out, wv); break;
           }
         } else {
-          rank_sort_big(P, lds, marks, bin_base, n, out);
+          rank_sort_big(P, lds, marks, bin_base, n, out, wv);
         }
         break;
     }
@@ -797,7 +827,7 @@ __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned l
   // bitonic sort of the bin's (key << 32 | record) words by all 256 threads
   uint32_t np = 64;
   while (np < n) np <<= 1;
-  for (uint32_t i = threadIdx.x; i < np; i += 256u) {
+  for (uint32_t i = tid; i < np; i += 256u) {
     unsigned long long v = ~0ull;
     if (i < n) {
       uint32_t ri = P.bins[bin_base + i];
@@ -808,7 +838,7 @@ __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned l
   __syncthreads();
   for (uint32_t k = 2; k <= np; k <<= 1) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t i = threadIdx.x; i < np; i += 256u) {
+      for (uint32_t i = tid; i < np; i += 256u) {
         uint32_t x = i ^ j;
         if (x > i) {
           unsigned long long a = s[i], b = s[x];
@@ -822,7 +852,7 @@ __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned l
       __syncthreads();
     }
   }
-  for (uint32_t i = threadIdx.x; i < n; i += 256u) out[i] = (uint32_t)s[i];
+  for (uint32_t i = tid; i < n; i += 256u) out[i] = (uint32_t)s[i];
   __threadfence_block();
   __syncthreads();
 }
@@ -840,12 +870,33 @@ constexpr uint32_t WAVE_C_BYTES = QUEUE_CAP * 8 + 256 * 8 + 64 * 16;  // queue |
 constexpr uint32_t PHASE_C_BYTES = LDS_C_OFF + 4 * WAVE_C_BYTES;
 constexpr uint32_t REC_COMMON = 0x80000000u;  // in a lane's winning record index: the key's common-case bit (record indices stay below 2^31)
 
+// The lane's pixel (rx, ry) in the tile and its word li in the tile's LDS images, made afresh from the thread index
+// where a later phase needs them.  Kept in registers from the top of the kernel they are the two values the allocator
+// spills, and a kernel with a scratch frame pays for it at every dispatch (2.5 us per launch, tools/gapbench.hip).
+__device__ __forceinline__ void lane_pixel(uint32_t wv, int& rx, int& ry, uint32_t& li) {
+  const uint32_t tid = tid_of(wv);
+  rx = (int)(((tid >> 6) & 1u) * 16u + (tid & 7u));
+  ry = (int)((tid >> 7) * 16u + ((tid >> 3) & 7u));
+  li = (uint32_t)ry * TILE + (uint32_t)rx;
+}
+
+// A 16-byte piece of a target row leaving the tile.  Non-temporal: the targets are written once per pass and not
+// read by it, and 100 MB of them per 4K frame otherwise sit dirty in the L2s until the end-of-kernel write-back and
+// push records and texels out (-1.5 % of the frame; the same hint on the geometry stage's record stores costs 0.7 %:
+// those are read back within the pass).
+__device__ __forceinline__ void store_row16(void* p, uint4 v) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
+}
+
 // QUARTER: this workgroup renders 8 rows of a split tile (svr_device.h SPLIT_*).  Its own instantiation, chosen
 // by blockIdx alone: sharing one body with run-time row ranges cost the whole-tile path 20-35 spilled
 // registers and 8-13 % of the frame, and choosing by a flag in tile_info put a dependent load in front of
 // every tile (+2 %).
 template <int FMT, bool INSTR, bool QUARTER, bool SPLIT>
-__device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, const uint4 i1, uint4* s_cov, uint32_t* s_idx, unsigned char* s_c) {
+__device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, const uint4 i1, uint4* s_cov, uint32_t* s_idx, unsigned char* s_c,
+                                          const uint32_t wv) {
   typedef Codec<FMT> CD;
   typedef typename CD::enc_t enc_t;
   // Workgroups are dispatched in blockIdx order: walk the tiles heaviest class first (fill_kernel's
@@ -953,16 +1004,19 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
   // it leaves now, straight from the visibility tile, as whole rows where the tile lies inside the scissor (16
   // bytes per lane, full 128-byte lines), and phase C's copy of the opaque depth is taken on the way.
   if (inside && aligned) {
-    const uint32_t row = threadIdx.x >> 3, c = (threadIdx.x & 7u) * 4u;
+    const uint32_t tid = tid_of(wv), row = tid >> 3, c = (tid & 7u) * 4u;
     uint4 z = make_uint4(0u, 0u, 0u, 0u);  // depth CLEAR 0.0
     if (n_op) {
       const uint4* src = reinterpret_cast<const uint4*>(s_depth + row * TILE + c);
       uint4 lo = src[0], hi = src[1];
       z = make_uint4(lo.y, lo.w, hi.y, hi.w);
     }
-    *reinterpret_cast<uint4*>(P.depth + (size_t)(ty0 + (int)row) * P.W + (size_t)(tx0 + (int)c)) = z;
+    store_row16(P.depth + (size_t)(ty0 + (int)row) * P.W + (size_t)(tx0 + (int)c), z);
     if (n_tr) *reinterpret_cast<uint4*>(s_z + row * TILE + c) = z;
   } else {
+    int rx, ry;
+    uint32_t li;
+    lane_pixel(wv, rx, ry, li);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const uint32_t w = li + (uint32_t)((k & 1) * 8 + (k >> 1) * 256);
@@ -981,8 +1035,7 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
   uint32_t generic_slots = 0;  // wave-uniform: pixel slots in which some lane needs the generic fragment stage
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    uint32_t tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
+    const uint32_t tid = tid_of(wv);
     const int qx = (int)(((tid >> 6) & 1u) * 16u + (tid & 7u)) + (k & 1) * 8, qy = (int)((tid >> 7) * 16u + ((tid >> 3) & 7u)) + (k >> 1) * 8;
     const int px = tx0 + qx, py = ty0 + qy;
     if (__all(!dirty[k] || (recs[k] & REC_COMMON))) {
@@ -1006,6 +1059,9 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
       if (!((generic_slots >> k) & 1u)) continue;
       uint32_t rec = (k == 0 ? recs[0] : (k == 1 ? recs[1] : (k == 2 ? recs[2] : recs[3]))) & ~REC_COMMON;
       bool d = k == 0 ? dirty[0] : (k == 1 ? dirty[1] : (k == 2 ? dirty[2] : dirty[3]));
+      int rx, ry;
+      uint32_t li;
+      lane_pixel(wv, rx, ry, li);
       int px = tx0 + rx + (k & 1) * 8, py = ty0 + ry + (k >> 1) * 8;
       if (d) {
         lc[li + (uint32_t)((k & 1) * 8 + (k >> 1) * 256)] = CD::encode(shade_pixel<false>(P, rec, px, py, nullptr));
@@ -1021,6 +1077,9 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
     enc_t cv;
     if constexpr (sizeof(enc_t) == 8) cv = enc_t(make_uint2(P.clear_lo, P.clear_hi));
     else cv = enc_t(P.clear_lo);
+    int rx, ry;
+    uint32_t li;
+    lane_pixel(wv, rx, ry, li);
 #pragma unroll
     for (int k = 0; k < 4; k++)
       if (!dirty[k] && pix_ok[k]) {
@@ -1036,26 +1095,29 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(s_c + LDS_C_OFF);
     if (QUARTER) {  // n_tr <= SORT_CAP: sorted in LDS, written out of place
       uint32_t* shared_list = reinterpret_cast<uint32_t*>(P.sort_arena + sort_base);
-      sort_bin_by_key<SPLIT>(P, scratch, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, shared_list);
+      sort_bin_by_key<SPLIT>(P, scratch, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, shared_list, wv);
       order = shared_list;
     } else if (n_tr <= SORT_CAP) {
-      sort_bin_by_key<SPLIT>(P, scratch, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, P.bins + tbase);
+      sort_bin_by_key<SPLIT>(P, scratch, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, P.bins + tbase, wv);
     } else {
-      sort_bin_by_key<SPLIT>(P, P.sort_arena + sort_base, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, P.bins + tbase);  // rare: a bin too large for LDS
+      sort_bin_by_key<SPLIT>(P, P.sort_arena + sort_base, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, P.bins + tbase, wv);  // rare: a bin too large for LDS
     }
+    int rx, ry;
+    uint32_t li;
+    lane_pixel(wv, rx, ry, li);
 #pragma unroll
     for (int k = 0; k < 4; k++)  // colour loadOp LOAD for what neither the opaque pass nor a clear has written
       if (!dirty[k] && pix_ok[k])
         lc[li + (uint32_t)((k & 1) * 8 + (k >> 1) * 256)] =
             reinterpret_cast<const enc_t*>(P.color)[(size_t)(ty0 + ry + (k >> 1) * 8) * P.W + (size_t)(tx0 + rx + (k & 1) * 8)];
-    unsigned char* mine = s_c + LDS_C_OFF + wave * WAVE_C_BYTES;
-    enc_t* col = lc + (uint32_t)(row0 + ((int)wave << lrpw)) * TILE;  // this wave's rows of the colour tile
+    unsigned char* mine = s_c + LDS_C_OFF + wv * WAVE_C_BYTES;
+    enc_t* col = lc + (uint32_t)(row0 + ((int)wv << lrpw)) * TILE;  // this wave's rows of the colour tile
     uint2* q = reinterpret_cast<uint2*>(mine);
     unsigned long long* mask = reinterpret_cast<unsigned long long*>(mine + QUEUE_CAP * 8);
     float4* s_src = reinterpret_cast<float4*>(mine + QUEUE_CAP * 8 + 256 * 8);
-    for (uint32_t i = lane; i < 256u; i += 64u) mask[i] = 0ull;
+    for (uint32_t i = tid_of(wv) & 63u; i < 256u; i += 64u) mask[i] = 0ull;
     // (the first barrier inside the scan orders these writes)
-    scan_columns_ordered<FMT, INSTR>(P, s_cov, s_idx, order, n_tr, tx0, ty0, row0, lrpw, s_z, col, q, mask, s_src, n_raster, n_shaded);
+    scan_columns_ordered<FMT, INSTR>(P, s_cov, s_idx, order, n_tr, tx0, ty0, row0, lrpw, s_z, col, q, mask, s_src, n_raster, n_shaded, wv);
 #pragma unroll
     for (int k = 0; k < 4; k++) dirty[k] = pix_ok[k];
   }
@@ -1067,15 +1129,18 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
   // 8-pixel row pieces of four 8x8 blocks: stored directly they reach memory as 32- and 64-byte partial
   // lines, which the memory side counted as twice the bytes.)
   const bool whole = dirty[0] && dirty[1] && dirty[2] && dirty[3];
-  if (__syncthreads_and(whole) && inside && aligned) {
+  if (!block_any<1>(!whole, wv) && inside && aligned) {
     constexpr uint32_t PX = 16u / sizeof(enc_t);  // pixels per 16-byte store
 #pragma unroll
-    for (uint32_t i = threadIdx.x; i < TILE * TILE / PX; i += 256u) {
+    for (uint32_t i = tid_of(wv); i < TILE * TILE / PX; i += 256u) {
       uint32_t row = i / (TILE / PX), c = (i % (TILE / PX)) * PX;
       uint4 v = *reinterpret_cast<const uint4*>(lc + row * TILE + c);
-      *reinterpret_cast<uint4*>(reinterpret_cast<enc_t*>(P.color) + (size_t)(ty0 + (int)row) * P.W + (size_t)(tx0 + (int)c)) = v;
+      store_row16(reinterpret_cast<enc_t*>(P.color) + (size_t)(ty0 + (int)row) * P.W + (size_t)(tx0 + (int)c), v);
     }
   } else {
+    int rx, ry;
+    uint32_t li;
+    lane_pixel(wv, rx, ry, li);
 #pragma unroll
     for (int k = 0; k < 4; k++)
       if (pix_ok[k] && dirty[k])
@@ -1084,7 +1149,7 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
   }
   if (stamps) {
     stamp[4] = clock64();
-    if (threadIdx.x == 0 && row0 == 0)  // of a split tile: its first quarter
+    if (tid_of(wv) == 0 && row0 == 0)  // of a split tile: its first quarter
       for (int k = 0; k < 4; k++) P.tile_cycles[tile * 4u + k] = (uint32_t)(stamp[k + 1] - stamp[k]);
   }
   if (INSTR) {
@@ -1130,6 +1195,7 @@ __global__ __launch_bounds__(256, SVR_TILE_WAVES) void tile_kernel(FrameParams P
   // behind the flags' round trip)
   asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3), "+s"(w4), "+s"(w5), "+s"(w6), "+s"(w7), "+s"(overflow), "+s"(poison), "+s"(n_split));
   const uint4 i0 = make_uint4(w0, w1, w2, w3), i1 = make_uint4(w4, w5, w6, w7);
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // this wave's number, for tid_of()
 
   if (blockIdx.x == 0 && threadIdx.x < P.tiles_y)  // the pass's cost per tile row, for the host (nobody waits for it)
     __hip_atomic_store(P.host_row_cost + threadIdx.x, P.row_cost[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1150,12 +1216,12 @@ __global__ __launch_bounds__(256, SVR_TILE_WAVES) void tile_kernel(FrameParams P
   } else if (SPLIT) {
     if (blockIdx.x < SPLIT_EXTRA) {  // the quarters of split tiles, as many as fill_kernel made
       if (blockIdx.x >= 4u * min(n_split, SPLIT_MAX)) return;
-      tile_body<FMT, INSTR, true, true>(P, i0, i1, s_cov, s_idx, s_c);
+      tile_body<FMT, INSTR, true, true>(P, i0, i1, s_cov, s_idx, s_c, wv);
     } else {
-      tile_body<FMT, INSTR, false, true>(P, i0, i1, s_cov, s_idx, s_c);
+      tile_body<FMT, INSTR, false, true>(P, i0, i1, s_cov, s_idx, s_c, wv);
     }
   } else {
-    tile_body<FMT, INSTR, false, false>(P, i0, i1, s_cov, s_idx, s_c);
+    tile_body<FMT, INSTR, false, false>(P, i0, i1, s_cov, s_idx, s_c, wv);
   }
 }
 

@@ -142,7 +142,7 @@ struct SvrContext {
     bool used = false;
   };
   static const int MAX_OPS = 8;  // operations in flight (log slots)
-  static const int NSETS = 2;  // three sets were tried: stage 1 is starved by the running tile kernel either way
+  static const int NSETS = 2;  // three sets were tried (again in round 2: +2 %): stage 1 is starved by the running tile kernel either way
   PassSet sets[NSETS];
   int set_pos = 0;
   // operation log (see "the operation log" below)
