@@ -227,8 +227,8 @@ __global__ __launch_bounds__(256) void fill_kernel(FrameParams P) {
         sort_base = atomicAdd(&P.counters->sort_used, np);
         if (sort_base + np > P.sort_cap) atomicOr(&P.counters->overflow, 4u);
       }
-      // heavy tile: four quarters (svr_device.h SPLIT_*).  Their common sorted transparent list lives in
-      // the sort arena: every quarter writes the same words there, none touches the bin itself.
+      // heavy tile: four quarters (svr_device.h SPLIT_*).  Each writes the sorted list of its own part of the
+      // transparent bin to its quarter of the tile's span of the sort arena; none touches the bin itself.
       bool split = !(P.tuning & TUNE_NO_SPLIT) && n_tr <= SPLIT_SORT_MAX &&
                    tile_cost(n_op, n_tr) > max(SPLIT_MIN_COST, P.counters->cost_sum / TILE_SLOTS);
       uint32_t sp = 0;
@@ -237,8 +237,9 @@ __global__ __launch_bounds__(256) void fill_kernel(FrameParams P) {
         split = sp < SPLIT_MAX;
       }
       if (split && n_tr) {
-        sort_base = atomicAdd(&P.counters->sort_used, (n_tr + 1u) >> 1);  // n_tr 32-bit words
-        if (sort_base + ((n_tr + 1u) >> 1) > P.sort_cap) atomicOr(&P.counters->overflow, 4u);
+        const uint32_t span = 4u * ((n_tr + 1u) >> 1);  // four lists of up to n_tr 32-bit words
+        sort_base = atomicAdd(&P.counters->sort_used, span);
+        if (sort_base + span > P.sort_cap) atomicOr(&P.counters->overflow, 4u);
       }
       const uint4 i0 = make_uint4(t, n_op, P.tile_offset[t], n_tr);
       const uint32_t off_tr = P.tile_offset[P.n_tiles + t];

@@ -787,6 +787,90 @@ __device__ __forceinline__ void rank_sort_big(const FrameParams& P, unsigned cha
   }
 }
 
+// A quarter of a split tile makes its OWN sorted list of the tile's transparent bin: only the triangles whose
+// bounding box meets the quarter's eight rows (and the tile's columns) are kept, ranked by key among themselves and
+// written to the quarter's span of the sort arena.  What it leaves out has no coverage in the quarter, so the ordered
+// scan sees the same fragments in the same order.  (Every quarter used to sort the whole bin and walk all of it: at
+// 1920x1080 the quarter of a tile that sees a curtain edge-on IS the frame — 1224 triangles, 232 K cycles in phase
+// C of which ~55 K the rank by counting, whose cost goes with the square of the list.)
+// lds: >= 16 KiB (keys, record indices); marks: [SORT_CAP] words elsewhere in LDS.  Returns the length of the list.
+__device__ __forceinline__ uint32_t sort_quarter_bin(const FrameParams& P, unsigned char* lds, uint32_t* marks, uint32_t bin_base, uint32_t n,
+                                                     int tx0, int qy0, int qrows, uint32_t* out, const uint32_t wv) {
+  __shared__ uint32_t kept;
+  const uint32_t tid = tid_of(wv);
+  uint32_t* k32 = reinterpret_cast<uint32_t*>(lds);  // [m] keys
+  uint32_t* r32 = k32 + SORT_CAP;                     // [m] record indices
+  if (tid == 0) kept = 0u;
+  __syncthreads();
+  {
+    uint32_t ri[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      uint32_t i = tid + 256u * k;
+      ri[k] = i < n ? P.bins[bin_base + i] : 0u;
+    }
+    uint2 box[8];
+    uint32_t key[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      uint32_t i = tid + 256u * k;
+      if (i < n) {
+        box[k] = *reinterpret_cast<const uint2*>(P.recs + ri[k]);
+        key[k] = P.recs[ri[k]].key;
+      } else {
+        box[k] = make_uint2(1u, 0u);  // minx 1 > maxx 0
+        key[k] = 0u;
+      }
+    }
+    const uint32_t lane = tid & 63u;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      if (256u * k >= n) break;  // uniform
+      const int minx = (int)(int16_t)(box[k].x & 0xffffu), miny = (int)(int16_t)(box[k].x >> 16);
+      const int maxx = (int)(int16_t)(box[k].y & 0xffffu), maxy = (int)(int16_t)(box[k].y >> 16);
+      const bool keep = min(maxx, tx0 + TILE - 1) >= max(minx, tx0) && min(maxy, qy0 + qrows - 1) >= max(miny, qy0);
+      const unsigned long long m = __ballot(keep);
+      uint32_t base = 0;
+      if (lane == 0 && m) base = atomicAdd(&kept, (uint32_t)__popcll(m));  // LDS
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (keep) {
+        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        k32[pos] = key[k];
+        r32[pos] = ri[k];
+        marks[pos] = 0u;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t m = kept;
+  if (m == 0u) return 0u;
+  for (uint32_t base = 0; base < m; base += 1024u) {  // four elements per thread at a time
+    switch (min((m - base + 255u) >> 8, 4u)) {
+      case 1: rank_pass<1>(k32, r32, marks, base, m, out, wv); break;
+      case 2: rank_pass<2>(k32, r32, marks, base, m, out, wv); break;
+      case 3: rank_pass<3>(k32, r32, marks, base, m, out, wv); break;
+      default: rank_pass<4>(k32, r32, marks, base, m, out, wv); break;
+    }
+  }
+  __syncthreads();
+  bool hole = false;
+  for (uint32_t r = tid; r < m; r += 256u) hole = hole || marks[r] == 0u;
+  if (block_any<0>(hole, wv)) {  // equal keys (the clipper's pieces of one triangle): rank (key, record) — their mutual order is free
+    for (uint32_t i = tid; i < m; i += 256u) {
+      const uint32_t mk = k32[i], mr = r32[i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < m; j++) {
+        uint32_t v = k32[j];
+        rank += (v < mk || (v == mk && r32[j] < mr)) ? 1u : 0u;
+      }
+      out[rank] = mr;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  return m;
+}
+
 // s: scratch — the LDS block (>= 16 KiB) for bins up to SORT_CAP, else the tile's span of the global sort arena,
 // the next power of two >= n words (fill_kernel reserved it; global memory is coherent inside a workgroup's CU).
 // out: where the sorted record indices go — the bin itself, or (quarters of a split tile, n <= RANK_SORT_MAX) the
@@ -896,7 +980,7 @@ __device__ __forceinline__ void store_row16(void* p, uint4 v) {
 // every tile (+2 %).
 template <int FMT, bool INSTR, bool QUARTER, bool SPLIT>
 __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, const uint4 i1, uint4* s_cov, uint32_t* s_idx, unsigned char* s_c,
-                                          const uint32_t wv) {
+                                          const uint32_t wv, const uint32_t wg_start = 0) {
   typedef Codec<FMT> CD;
   typedef typename CD::enc_t enc_t;
   // Workgroups are dispatched in blockIdx order: walk the tiles heaviest class first (fill_kernel's
@@ -1093,15 +1177,17 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
     uint32_t tbase = off_tr;
     const uint32_t* order = P.bins + tbase;
     unsigned long long* scratch = reinterpret_cast<unsigned long long*>(s_c + LDS_C_OFF);
-    if (QUARTER) {  // n_tr <= SORT_CAP: sorted in LDS, written out of place
-      uint32_t* shared_list = reinterpret_cast<uint32_t*>(P.sort_arena + sort_base);
-      sort_bin_by_key<SPLIT>(P, scratch, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, shared_list, wv);
-      order = shared_list;
+    uint32_t n_list = n_tr;
+    if (QUARTER) {  // n_tr <= SORT_CAP: the quarter's own part of the bin, sorted in LDS, written to its span of the arena
+      uint32_t* own_list = reinterpret_cast<uint32_t*>(P.sort_arena + sort_base + (uint32_t)(row0 >> 3) * ((n_tr + 1u) >> 1));
+      n_list = sort_quarter_bin(P, reinterpret_cast<unsigned char*>(scratch), reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, tx0, sub_y0, nrows, own_list, wv);
+      order = own_list;
     } else if (n_tr <= SORT_CAP) {
       sort_bin_by_key<SPLIT>(P, scratch, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, P.bins + tbase, wv);
     } else {
       sort_bin_by_key<SPLIT>(P, P.sort_arena + sort_base, reinterpret_cast<uint32_t*>(s_cov), tbase, n_tr, P.bins + tbase, wv);  // rare: a bin too large for LDS
     }
+    if (n_list) {  // (a quarter none of the bin's triangles reaches leaves its pixels as they are)
     int rx, ry;
     uint32_t li;
     lane_pixel(wv, rx, ry, li);
@@ -1117,9 +1203,10 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
     float4* s_src = reinterpret_cast<float4*>(mine + QUEUE_CAP * 8 + 256 * 8);
     for (uint32_t i = tid_of(wv) & 63u; i < 256u; i += 64u) mask[i] = 0ull;
     // (the first barrier inside the scan orders these writes)
-    scan_columns_ordered<FMT, INSTR>(P, s_cov, s_idx, order, n_tr, tx0, ty0, row0, lrpw, s_z, col, q, mask, s_src, n_raster, n_shaded, wv);
+    scan_columns_ordered<FMT, INSTR>(P, s_cov, s_idx, order, n_list, tx0, ty0, row0, lrpw, s_z, col, q, mask, s_src, n_raster, n_shaded, wv);
 #pragma unroll
     for (int k = 0; k < 4; k++) dirty[k] = pix_ok[k];
+    }
   }
 
   if (stamps) stamp[3] = clock64();
@@ -1149,8 +1236,16 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
   }
   if (stamps) {
     stamp[4] = clock64();
-    if (tid_of(wv) == 0 && row0 == 0)  // of a split tile: its first quarter
+    if (tid_of(wv) == 0 && row0 == 0) {  // of a split tile: its first quarter
+#ifdef SVR_DEBUG_WG_TIMES  // development build (tools/frames.py --wgtimes): when and where the workgroup ran, not its phases
+      P.tile_cycles[tile * 4u + 0] = wg_start;
+      P.tile_cycles[tile * 4u + 1] = (uint32_t)wall_clock64();
+      P.tile_cycles[tile * 4u + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+      P.tile_cycles[tile * 4u + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+#else
       for (int k = 0; k < 4; k++) P.tile_cycles[tile * 4u + k] = (uint32_t)(stamp[k + 1] - stamp[k]);
+#endif
+    }
   }
   if (INSTR) {
     for (int off = 32; off > 0; off >>= 1) {
@@ -1184,6 +1279,11 @@ __global__ __launch_bounds__(256, SVR_TILE_WAVES) void tile_kernel(FrameParams P
   // — flags, branch, tile id by a vector load, the other fields by a second one — in front of every tile's
   // bin -> record chain: ~2 K of a light tile's 33 K cycles.)  Constant address space = scalar loads; all of
   // it was written by earlier kernels.
+#ifdef SVR_DEBUG_WG_TIMES
+  const uint32_t wg_start = (uint32_t)wall_clock64();
+#else
+  const uint32_t wg_start = 0;
+#endif
   const uint32_t slot = SPLIT ? blockIdx.x : SPLIT_EXTRA + blockIdx.x;
   typedef const __attribute__((address_space(4))) uint32_t* const_words;
   const_words ti = (const_words)(const void*)P.tile_info + 8u * slot;
@@ -1216,12 +1316,12 @@ __global__ __launch_bounds__(256, SVR_TILE_WAVES) void tile_kernel(FrameParams P
   } else if (SPLIT) {
     if (blockIdx.x < SPLIT_EXTRA) {  // the quarters of split tiles, as many as fill_kernel made
       if (blockIdx.x >= 4u * min(n_split, SPLIT_MAX)) return;
-      tile_body<FMT, INSTR, true, true>(P, i0, i1, s_cov, s_idx, s_c, wv);
+      tile_body<FMT, INSTR, true, true>(P, i0, i1, s_cov, s_idx, s_c, wv, wg_start);
     } else {
-      tile_body<FMT, INSTR, false, true>(P, i0, i1, s_cov, s_idx, s_c, wv);
+      tile_body<FMT, INSTR, false, true>(P, i0, i1, s_cov, s_idx, s_c, wv, wg_start);
     }
   } else {
-    tile_body<FMT, INSTR, false, false>(P, i0, i1, s_cov, s_idx, s_c, wv);
+    tile_body<FMT, INSTR, false, false>(P, i0, i1, s_cov, s_idx, s_c, wv, wg_start);
   }
 }
 

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--tex-size", type=int, default=1024)
     ap.add_argument("--instances", type=int, default=1)
     ap.add_argument("--frames", type=int, default=20)
+    ap.add_argument("--wgtimes", action="store_true", help="with a -DSVR_DEBUG_WG_TIMES build (--lib): where the tile kernel's time goes between workgroups")
     ap.add_argument("--hist", action="store_true")
     ap.add_argument("--flatten", type=int, default=0, help="SVR_OPT_DEVICE_FLATTEN: 0 auto, 1 device, 2 host")
     ap.add_argument("--timing", type=int, default=2, help="SVR_OPT_KERNEL_TIMING during the frames (2 = events around every stage, perturbs the pipeline; 0 for traces)")
@@ -88,6 +89,55 @@ def main():
         host.append(r.draw_geometry(scene, opaque, transparent).mesh_draw_time)
         r.sync()
     print(f"  host record time with an idle GPU: median {float(np.median(host)):.3f} ms")
+    if args.wgtimes:
+        r.set_option(A.OPT_TILE_CYCLES, 1)
+        for _ in range(4):
+            r.clear_color((1, 1, 1, 1))
+            r.draw_geometry(scene, opaque, transparent)
+        r.sync()
+        w = r.read_tile_cycles()
+        r.set_option(A.OPT_TILE_CYCLES, 0)
+        start, end, hw, xcc = (w[:, k].astype(np.int64) for k in range(4))
+        ok = end != 0
+        start, end, hw, xcc = start[ok], end[ok], hw[ok], xcc[ok] & 15
+        t0 = start.min()
+        start, end = (start - t0) / 100.0, (end - t0) / 100.0  # us (100 MHz wall clock)
+        cu = (xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)  # xcc, se, sh, cu
+        span = end.max()
+        busy = (end - start).sum()
+        ncu = len(np.unique(cu))
+        print(f"  tile kernel by workgroup: {start.size} workgroups on {ncu} CUs; first start .. last end {span:.1f} us; "
+              f"sum of residence {busy / 1e3:.1f} ms = {busy / (4 * ncu):.1f} us per slot at 4 per CU")
+        # resident workgroups per CU over time
+        grid = np.arange(0.0, span, 1.0)
+        resident = np.zeros(grid.size)
+        for a, b in zip(start, end):
+            resident[int(a):int(np.ceil(b))] += 1
+        resident /= ncu
+        marks = [int(x) for x in np.linspace(0, grid.size - 1, 24)]
+        print("  mean resident workgroups per CU at", [f"{grid[m]:.0f}us:{resident[m]:.2f}" for m in marks])
+        full = np.nonzero(resident > 3.9)[0]
+        if full.size:
+            print(f"  chip full (>3.9 per CU) from {grid[full[0]]:.0f} to {grid[full[-1]]:.0f} us; lost slot-time before {np.sum(4 - resident[:full[0]]) / 4:.1f} us-equivalents, "
+                  f"after {np.sum(4 - resident[full[-1]:]) / 4:.1f}, in between {np.sum(4 - resident[full[0]:full[-1]]) / 4:.1f}")
+        # hand-over on a CU: from a workgroup's end to the next start on that CU (greedy matching in time order)
+        gaps = []
+        for c in np.unique(cu):
+            m = cu == c
+            ev = sorted([(t, 1) for t in end[m]] + [(t, 0) for t in start[m]])
+            free = []
+            for t, is_end in ev:
+                if is_end:
+                    free.append(t)
+                elif free:
+                    gaps.append(t - free.pop(0))
+        gaps = np.array(gaps)
+        if gaps.size:
+            print(f"  hand-over of a CU slot (a workgroup ends -> the next starts there): {gaps.size} hand-overs, median {np.median(gaps):.2f} us, "
+                  f"mean {gaps.mean():.2f}, p90 {np.percentile(gaps, 90):.2f}, sum {gaps.sum() / 1e3:.2f} ms = {gaps.sum() / (4 * ncu):.1f} us per slot")
+        dur = end - start
+        print(f"  workgroup residence: median {np.median(dur):.1f} us, p90 {np.percentile(dur, 90):.1f}, max {dur.max():.1f}; the last 5 % of workgroups start after "
+              f"{np.percentile(start, 95):.0f} us")
     if args.hist:
         op, tr = r.read_bins()
         for name, c in (("opaque", op), ("transparent", tr)):

@@ -47,6 +47,15 @@ __global__ __launch_bounds__(256) void spin_write(unsigned long long ticks, uint
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
+__global__ void publish(unsigned int* flag, unsigned int value) { __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(64) void gate(const unsigned int* flag, unsigned int want) {
+  // one wave: cannot starve the producer of the flag.  Bounded: gives up after ~100 ms.
+  unsigned long long t0 = wall_clock64();
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0 && wall_clock64() - t0 < 10000000ull)
+    __builtin_amdgcn_s_sleep(2);
+}
+
 static double now_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -136,6 +145,45 @@ int main() {
              : variant == 1 ? "two streams: WITHOUT the tile kernel's wait for its bins (timing only)"
                             : "two streams: pipeline, tile event by hipEventRecord",
              now_us() - t, 100.0, LINKS);
+    }
+    // 5b. the tile kernel's wait as a stream memory operation on a device word / as a one-wave gate kernel
+    {
+      static unsigned int* flag = nullptr;
+      static unsigned int epoch = 0;
+      if (!flag) {
+        CHECK(hipMalloc(&flag, 64));
+        CHECK(hipMemset(flag, 0, 64));
+      }
+      for (int variant = 0; variant < 3; variant++) {
+        CHECK(hipDeviceSynchronize());
+        t = now_us();
+        bool ok = true;
+        for (int i = 0; i < LINKS && ok; i++) {
+          epoch++;
+          if (i >= 2) CHECK(hipStreamWaitEvent(g, ev_tile[(i - 2) % RING], 0));
+          hipLaunchKernelGGL(spin, dim3(256), block, 0, g, T_SHORT, nullptr);
+          if (variant == 0) {
+            if (hipStreamWriteValue32(g, flag, epoch, 0) != hipSuccess || hipStreamWaitValue32(s, flag, epoch, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) {
+              printf("stream memory operations are not supported here\n");
+              ok = false;
+              (void)hipGetLastError();
+              break;
+            }
+          } else if (variant == 1) {
+            hipLaunchKernelGGL(publish, dim3(1), dim3(1), 0, g, flag, epoch);
+            hipLaunchKernelGGL(gate, dim3(1), dim3(64), 0, s, flag, epoch);
+          } else {
+            hipLaunchKernelGGL(publish, dim3(1), dim3(1), 0, g, flag, epoch);  // the consumer would check the word itself
+          }
+          hipExtLaunchKernelGGL(spin, grid, block, 0, s, nullptr, ev_tile[i % RING], 0, T_LONG, nullptr);
+        }
+        CHECK(hipDeviceSynchronize());
+        if (ok)
+          report(variant == 0   ? "two streams: wait as hipStreamWaitValue32 on a device word"
+                 : variant == 1 ? "two streams: wait as a one-wave gate kernel on a device word"
+                                : "two streams: no wait, a publish kernel behind stage 1 (timing only)",
+                 now_us() - t, 100.0, LINKS);
+      }
     }
     // 6. the same with stage 1 as six short kernels (5 us each)
     CHECK(hipDeviceSynchronize());
