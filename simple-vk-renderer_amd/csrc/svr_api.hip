@@ -142,7 +142,7 @@ struct SvrContext {
     bool used = false;
   };
   static const int MAX_OPS = 8;  // operations in flight (log slots)
-  static const int NSETS = 2;  // three sets were tried (again in round 2: +2 %): stage 1 is starved by the running tile kernel either way
+  static const int NSETS = 4;  // stage 1 of a small pass may run three passes ahead of the tile stage; a large one keeps to one (submit_pass)
   PassSet sets[NSETS];
   int set_pos = 0;
   // operation log (see "the operation log" below)
@@ -186,6 +186,9 @@ struct SvrContext {
   uint32_t* h_failed_seq = nullptr;  // pinned; written by the tile kernel of the first failing pass
   uint32_t* d_poison = nullptr;  // sticky device flag: a pass overflowed, later target writes are void
   hipStream_t gstream = nullptr;
+  hipStream_t gstream_hi = nullptr;   // the same at the highest priority: stage 1 of small passes (submit_pass)
+  hipStream_t last_g = nullptr;       // the one the previous pass used
+  hipEvent_t ev_gswitch = nullptr;
   DevBuf d_cvt;
   uint32_t clip_cap = 0, extra_cap = 0, bin_cap = 0;
   uint32_t debug_caps = 0;  // SVR_OPT_QUEUE_CAPS
@@ -455,7 +458,18 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   const int set_index = ctx->set_pos;
   ctx->set_pos = (ctx->set_pos + 1) % SvrContext::NSETS;
   SvrContext::PassSet& set = ctx->sets[set_index];
-  hipStream_t s = ctx->stream, g = pipe ? ctx->gstream : ctx->stream;
+  // Stage 1 of a pass of few tiles (a 1920x1080 frame, a band of a sharded one) runs at the highest stream priority:
+  // such a pass is bounded by stage 1 — its setup kernel finds the CUs taken by the tile kernel's first, longest
+  // workgroups (21 us alone, 53 us beside it) — and with priority its workgroups get the slots that come free
+  // (1080p: -5 % per frame).  A 4K frame is bounded by its tile kernel and loses 0.8 % to the same favour.
+  hipStream_t s = ctx->stream, g = pipe ? (P.n_tiles <= SPLIT_TILES_MAX ? ctx->gstream_hi : ctx->gstream) : ctx->stream;
+  if (pipe) {
+    if (ctx->last_g && ctx->last_g != g) {  // keep stage 1 of consecutive passes in order across the two streams
+      HIPCHK(hipEventRecord(ctx->ev_gswitch, ctx->last_g));
+      HIPCHK(hipStreamWaitEvent(g, ctx->ev_gswitch, 0));
+    }
+    ctx->last_g = g;
+  }
   // per-pass inputs: draws + chunks through pinned staging, one copy
   const size_t n_objects = flat_op ? flat_op->objects.size() : 0;
   size_t draw_bytes = (flat_op ? n_objects : draws.size()) * sizeof(DrawDesc), chunk_bytes = (size_t)P.n_chunks * sizeof(WaveChunk);
@@ -463,8 +477,16 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   if (flat_op)
     if (int e = set.flat.ensure(n_objects * 16 + 64)) return e;
   if (int e = bind_pass_buffers(ctx, P, set_index)) return e;
-  // this set was last read by the tile stage of NSETS passes ago
-  if (pipe && set.used) HIPCHK(hipStreamWaitEvent(g, set.ev_tile, 0));
+  // How far stage 1 runs ahead.  A pass of few tiles (a band of a sharded frame: stage 1 56 us, tiles 50 us) is bounded
+  // by stage 1, which then wants to run back to back: it only waits for its set, last read by the tile stage of
+  // NSETS passes ago (a band of an eight-way split: -16 % per frame against two sets, with the priority above).  A 4K
+  // frame is bounded by its tile kernel, and stage-1 kernels that arrive earlier only take CU time from it (+0.6 %):
+  // it waits for the tile stage of two passes back (which is behind that of NSETS passes ago in the stream).
+  if (pipe) {
+    SvrContext::PassSet& gate = P.n_tiles > SPLIT_TILES_MAX ? ctx->sets[(set_index + SvrContext::NSETS - 2) % SvrContext::NSETS] : set;
+    if (gate.used) HIPCHK(hipStreamWaitEvent(g, gate.ev_tile, 0));
+    else if (set.used) HIPCHK(hipStreamWaitEvent(g, set.ev_tile, 0));
+  }
   void* stage = nullptr;
   if (int e = stage_buffer(ctx, op_slot, (flat_op ? n_objects * sizeof(SvrRenderObject) : draw_bytes + chunk_bytes) + 64, &stage)) return e;
   P.host_counters = &ctx->h_counters[op_slot];
@@ -582,6 +604,7 @@ int submit_clear(SvrContext* ctx, const SvrContext::LoggedOp& op) {  // every lo
 int recover_from_overflow(SvrContext* ctx) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->gstream));
+  HIPCHK(hipStreamSynchronize(ctx->gstream_hi));
   const uint32_t failed_seq = *(volatile uint32_t*)ctx->h_failed_seq;
   *ctx->h_failed_seq = 0;
   for (SvrContext::LoggedOp& op : ctx->log) {
@@ -914,6 +937,12 @@ int svr_create(const SvrConfig* cfg, SvrContext** out) {
   // (A high-priority stream was tried for stage 1 and changes nothing: the workgroup dispatcher keeps
   // feeding the tile kernel that is already running, whatever the queue priority.)
   if ((r = hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking)) != hipSuccess) return bail(r, "hipStreamCreate");
+  {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if ((r = hipStreamCreateWithPriority(&ctx->gstream_hi, hipStreamNonBlocking, greatest)) != hipSuccess) return bail(r, "hipStreamCreate");
+    if ((r = hipEventCreateWithFlags(&ctx->ev_gswitch, hipEventDisableTiming)) != hipSuccess) return bail(r, "hipEventCreate");
+  }
   for (int i = 0; i < SvrContext::NSETS; i++) {
     if ((r = hipEventCreateWithFlags(&ctx->sets[i].ev_bin, hipEventDisableTiming)) != hipSuccess) return bail(r, "hipEventCreate");
   }
@@ -936,6 +965,7 @@ void svr_destroy(SvrContext* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->gstream) (void)hipStreamSynchronize(ctx->gstream);
+  if (ctx->gstream_hi) (void)hipStreamSynchronize(ctx->gstream_hi);
   for (auto& m : ctx->meshes) {
     if (m.vtx) (void)hipFree(m.vtx);
     if (m.idx) (void)hipFree(m.idx);
@@ -949,6 +979,8 @@ void svr_destroy(SvrContext* ctx) {
     if (set.ev_bin) (void)hipEventDestroy(set.ev_bin);
   }
   if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
+  if (ctx->gstream_hi) (void)hipStreamDestroy(ctx->gstream_hi);
+  if (ctx->ev_gswitch) (void)hipEventDestroy(ctx->ev_gswitch);
   for (DevBuf* b : bufs) b->release();
   for (int i = 0; i < SvrContext::MAX_OPS; i++)
     if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);

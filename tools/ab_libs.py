@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--frames", type=int, default=40)
     ap.add_argument("--tuning", type=int, default=0)
     ap.add_argument("--stages", action="store_true")
+    ap.add_argument("--band", default="", help="y0,rows: render only these rows (scissor), as one rank of a sharded frame does")
     args = ap.parse_args()
     pkg = g.load_package()
     import torch  # noqa: F401  (one HIP runtime per process: torch's is loaded first)
@@ -42,6 +43,9 @@ def main():
         handles = sc.upload(r)
         opaque, transparent = sc.render_objects(handles, instance_transforms=inst)
         r.set_option(A.OPT_TUNING, int(tun) if tun else args.tuning)
+        if args.band:
+            y0, rows = (int(v) for v in args.band.split(","))
+            r.set_scissor(0, y0, args.width, rows)
         ctx.append((spec, r, opaque, transparent))
     res = {i: [] for i in range(len(ctx))}
     for rnd in range(args.rounds + 1):
