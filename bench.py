@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--gather-fp16", action="store_true", help="N > 1: all-gather the RGBA16F target instead of the swapchain image")
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=25, help="repetitions of the timed --steps block (the median block is reported)")
-    ap.add_argument("--profile-tag", default="r02_f", help="profiles/<tag>_traffic.json and <tag>_valu.json of this build are quoted in the line")
+    ap.add_argument("--profile-tag", default="r02_g", help="profiles/<tag>_traffic.json and <tag>_valu.json of this build are quoted in the line")
     return ap.parse_args()
 
 
@@ -114,8 +114,8 @@ def cpu_baseline(args, pkg, shaded_per_frame, sc):
     dt_one = frames(1)
     r.close()
     return {"value": shaded_per_frame / dt_all, "unit": "fragments/s", "cores": cores, "kind": "port",
-            "description": "scalar C++ oracle (-O2, no intrinsics, -ffp-contract=off), forward rasteriser, UNBINNED: every 16-row band "
-                           "walks every triangle; geometry single-threaded, rasterisation band-parallel",
+            "description": "scalar C++ oracle (-O2, no intrinsics, -ffp-contract=off), forward rasteriser without tiles: geometry on one "
+                           "thread, then 16-row bands over the threads, each walking the triangles that reach it in submission order",
             "frames_per_s": 1.0 / dt_all,
             "single_thread": {"value": shaded_per_frame / dt_one, "frames_per_s": 1.0 / dt_one, "cores": 1},
             "hardware_concurrency": hw, "cpu_model": model,

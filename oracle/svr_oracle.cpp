@@ -539,32 +539,37 @@ void process_triangle(PassState& ps, VOut v[3], const DrawCmd& cmd) {
   }
 }
 
-void run_geometry(PassState& ps, const SvrSceneData* scene, const std::vector<DrawCmd>& cmds) {
-  for (const DrawCmd& cmd : cmds) {
-    if (cmd.kind == PIPE_COLORED_TRIANGLE) {
-      VOut v[3];
-      for (int i = 0; i < 3; i++) colored_triangle_vert(i, v[i]);
-      ps.cur_key++;
-      process_triangle(ps, v, cmd);
-      continue;
-    }
-    float mvp[16];
-    if (cmd.kind == PIPE_MESH) matmul4(scene->viewproj, cmd.mat, mvp);
-    const Mesh& mesh = *cmd.mesh;
-    uint32_t ntri = cmd.index_count / 3;
-    for (uint32_t t = 0; t < ntri; t++) {
-      VOut v[3];
-      for (int k = 0; k < 3; k++) {
-        const SvrVertex& vx = mesh.vtx[mesh.idx[cmd.first_index + 3 * t + k]];
-        if (cmd.kind == PIPE_MESH)
-          mesh_vert(vx, mvp, cmd.mat, cmd.material->color_factors, v[k]);
-        else
-          colored_triangle_mesh_vert(vx, cmd.mat, v[k]);
-      }
-      ps.cur_key++;
-      process_triangle(ps, v, cmd);
-    }
+// one draw: its triangles in index order, appended to ps (ps.cur_key = sequence number of the draw's first triangle - 1)
+void run_draw(PassState& ps, const SvrSceneData* scene, const DrawCmd& cmd) {
+  if (cmd.kind == PIPE_COLORED_TRIANGLE) {
+    VOut v[3];
+    for (int i = 0; i < 3; i++) colored_triangle_vert(i, v[i]);
+    ps.cur_key++;
+    process_triangle(ps, v, cmd);
+    return;
   }
+  float mvp[16];
+  if (cmd.kind == PIPE_MESH) matmul4(scene->viewproj, cmd.mat, mvp);
+  const Mesh& mesh = *cmd.mesh;
+  uint32_t ntri = cmd.index_count / 3;
+  for (uint32_t t = 0; t < ntri; t++) {
+    VOut v[3];
+    for (int k = 0; k < 3; k++) {
+      const SvrVertex& vx = mesh.vtx[mesh.idx[cmd.first_index + 3 * t + k]];
+      if (cmd.kind == PIPE_MESH)
+        mesh_vert(vx, mvp, cmd.mat, cmd.material->color_factors, v[k]);
+      else
+        colored_triangle_mesh_vert(vx, cmd.mat, v[k]);
+    }
+    ps.cur_key++;
+    process_triangle(ps, v, cmd);
+  }
+}
+
+void run_geometry(PassState& ps, const SvrSceneData* scene, const std::vector<DrawCmd>& cmds) {
+  // (single-threaded also when the rasteriser is not: worked on side by side the draws' lists have to be joined
+  // afterwards, and moving 786 K records costs what the threads saved)
+  for (const DrawCmd& cmd : cmds) run_draw(ps, scene, cmd);
 }
 
 // ---------------------------------------------------------------- fragment stage
@@ -648,10 +653,14 @@ inline void store_color(SvrContext* ctx, size_t p, const float c[4]) {
 }
 
 // rasterise rows [y0,y1) of every triangle, in submission order
+// subset (may be null): the indices, ascending, of the triangles that reach rows y0 .. y1 - 1 — the threaded path
+// hands every band its own list; submission order within a pixel is the order of `tris` either way.
 void raster_rows(SvrContext* ctx, const SvrSceneData* scene, const std::vector<SetupTri>& tris,
-                 int y0, int y1, uint64_t& n_raster, uint64_t& n_shaded) {
+                 int y0, int y1, uint64_t& n_raster, uint64_t& n_shaded, const std::vector<uint32_t>* subset = nullptr) {
   uint32_t W = ctx->W;
-  for (const SetupTri& t : tris) {
+  const size_t count = subset ? subset->size() : tris.size();
+  for (size_t ti = 0; ti < count; ti++) {
+    const SetupTri& t = tris[subset ? (*subset)[ti] : ti];
     int ya = std::max(t.miny, y0), yb = std::min(t.maxy, y1 - 1);
     for (int py = ya; py <= yb; py++) {
       for (int px = t.minx; px <= t.maxx; px++) {
@@ -709,6 +718,14 @@ int run_pass(SvrContext* ctx, const SvrSceneData* scene, const std::vector<DrawC
   } else {
     const int band = 16;
     int nbands = (y1 - y0 + band - 1) / band;
+    // every band's triangles, in submission order (one pass over the list; a band used to walk all of it)
+    std::vector<std::vector<uint32_t>> reach((size_t)nbands);
+    for (size_t i = 0; i < ps.tris.size(); i++) {
+      const SetupTri& t = ps.tris[i];
+      int ya = std::max(t.miny, y0), yb = std::min(t.maxy, y1 - 1);
+      if (ya > yb || t.minx > t.maxx) continue;
+      for (int b = (ya - y0) / band; b <= (yb - y0) / band; b++) reach[(size_t)b].push_back((uint32_t)i);
+    }
     std::atomic<int> next{0};
     std::vector<uint64_t> nr(nthreads, 0), ns(nthreads, 0);
     std::vector<std::thread> pool;
@@ -718,7 +735,7 @@ int run_pass(SvrContext* ctx, const SvrSceneData* scene, const std::vector<DrawC
           int b = next.fetch_add(1);
           if (b >= nbands) break;
           int ya = y0 + b * band, yb = std::min(y1, ya + band);
-          raster_rows(ctx, scene, ps.tris, ya, yb, nr[ti], ns[ti]);
+          raster_rows(ctx, scene, ps.tris, ya, yb, nr[ti], ns[ti], &reach[(size_t)b]);
         }
       });
     }

@@ -75,6 +75,9 @@ def main():
             r.set_option(A.OPT_KERNEL_TIMING, 0)
             print(f"{path}: geometry/binning/tile median {np.median(np.array(acc), axis=0).round(4).tolist()} ms")
 
+    for _path, r, *_rest in ctx:
+        r.close()
+
 
 if __name__ == "__main__":
     main()

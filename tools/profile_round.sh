@@ -1,11 +1,11 @@
 #!/bin/bash
-# GPU box: everything profiles/<tag>_* is made from, for the build in the tree.   tools/profile_round.sh r02_f
+# GPU box: everything profiles/<tag>_* is made from, for the build in the tree.   tools/profile_round.sh r02_g
 #   <tag>_kernel_stats.csv   rocprofv3 --kernel-trace (per-kernel durations of bench.py's own command line)
 #   <tag>_pmc.txt            rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*), one counter group per run, kernel trace only
 #   <tag>_traffic.json / <tag>_valu.json   what bench.py quotes in roofline.traffic / roofline_valu
 #   <tag>_solo_kernel_stats.csv            the same kernels with the two stages serialised (SVR_OPT_TUNING bit 1): solo durations
 #   <tag>_bench.json         the bench line itself (run last, unprofiled)
-tag=${1:-r02_f}
+tag=${1:-r02_g}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/$tag
 rm -rf $out; mkdir -p $out
@@ -23,6 +23,7 @@ python3 tools/kstats_csv.py $(db kt) "rocprofv3 --kernel-trace -- python bench.p
 python3 tools/kstats_csv.py $(db solo) "rocprofv3 --kernel-trace -- python tools/frames.py --frames 30 --timing 0 --tuning 2 (geometry + binning and tiles serialised: solo durations)" > $out/${tag}_solo_kernel_stats.csv
 { echo "# rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 20 --warmup 5 --blocks 3 --no-cpu-baseline  (separate passes; FETCH_SIZE/WRITE_SIZE in KiB per launch, SQ_* quad-cycles / instructions per launch; tools/pmc_summary.py)"; python3 tools/pmc_summary.py $(db f) $(db w) $(db q1) $(db q2); } > $out/${tag}_pmc.txt
 python3 tools/profile_json.py $out/${tag}_pmc.txt $out/${tag}_kernel_stats.csv $tag $out
+cp $out/${tag}_traffic.json $out/${tag}_valu.json $root/profiles/  # (the box's copy of the tree: bench.py quotes them)
 python3 bench.py --profile-tag $tag > $out/${tag}_bench.json 2> $out/bench.err
 rm -rf $out/kt $out/f $out/w $out/q1 $out/q2 $out/solo
 ls -la $out; tail -c 1500 $out/${tag}_bench.json
