@@ -252,6 +252,17 @@ def test_scissor_bands_tile_the_frame(hip, oracle):
         assert np.all(band["depth"][:y0] == 0) and np.all(band["depth"][y1:] == 0)
 
 
+def test_quarters_with_clipped_transparent_triangles(hip, oracle):
+    """Cameras inside the curtains' planes, looking along them: the near plane cuts transparent triangles, whose pieces
+    share a key (the tie path of the rank sort), in tiles deep enough to be split into quarters, each of which sorts
+    only the part of the bin that reaches its rows.  The frame is the oracle's; whole tiles give it too."""
+    for k, cam in enumerate((((6.0, 11.0, 6.02), 0.0, 1.5708), ((5.2, 12.5, -5.97), -0.2, 1.5708), ((34.0, 9.5, 6.05), 0.15, 4.7124))):
+        a, b = both(T.render_sponza, hip, oracle, 960, 540, lod=1, tex_size=64, camera=cam, instrument=True)
+        assert_same(a, b, f"camera {k} inside a curtain")
+        c = T.render_sponza(hip, 960, 540, lod=1, tex_size=64, camera=cam, instrument=True, tuning=8)
+        assert_same(a, c, f"camera {k}: quarters vs whole tiles")
+
+
 def test_split_tiles_change_nothing(hip):
     """SVR_OPT_TUNING bit 3 keeps heavy tiles whole; the quarters of split tiles give the same frame.  (At this size
     the curtain tiles hold hundreds of transparent triangles and the pass's mean load per slot is small: they split.)"""
