@@ -187,6 +187,7 @@ class Renderer:
         h = C.c_void_p()
         lib.check(lib.lib.svr_create(C.byref(cfg), C.byref(h)))
         self.h = h
+        self._clear_args, self._object_args = {}, {}
 
     def close(self):
         if self.h:
@@ -256,7 +257,13 @@ class Renderer:
         return c.value, d.value
 
     def clear_color(self, rgba=(1.0, 1.0, 1.0, 1.0)):
-        self.lib.check(self.lib.lib.svr_clear_color(self.h, _f4(rgba)))
+        key = tuple(rgba)
+        arr = self._clear_args.get(key)  # the same few colours frame after frame: keep their ctypes arrays
+        if arr is None:
+            if len(self._clear_args) > 16:
+                self._clear_args.clear()
+            arr = self._clear_args[key] = _f4(rgba)
+        self.lib.check(self.lib.lib.svr_clear_color(self.h, arr))
 
     def draw_background(self, effect, data):
         """effect: BACKGROUND_GRADIENT / BACKGROUND_SKY; data: the 16 floats of ComputePushConstants."""
@@ -274,12 +281,27 @@ class Renderer:
     def set_scissor(self, x, y, w, h):
         self.lib.check(self.lib.lib.svr_set_scissor(self.h, x, y, w, h))
 
+    def _objects(self, a):
+        """(address, count) of a RenderObject list; arrays of the right kind are passed as they are, and their address is
+        remembered (ndarray.ctypes builds an object per access: microseconds that count against a 50-us band)."""
+        if a is None:
+            return 0, 0
+        if not (isinstance(a, np.ndarray) and a.dtype == RENDER_OBJECT_DTYPE and a.flags.c_contiguous):
+            a = np.ascontiguousarray(a, dtype=RENDER_OBJECT_DTYPE)
+            self._keep = (getattr(self, "_keep", ()) + (a,))[-2:]  # alive for the duration of the call
+            return a.ctypes.data, a.size
+        hit = self._object_args.get(id(a))
+        if hit is None or hit[0] is not a:
+            if len(self._object_args) > 8:
+                self._object_args.clear()
+            hit = self._object_args[id(a)] = (a, a.ctypes.data, a.size)
+        return hit[1], hit[2]
+
     def draw_geometry(self, scene, opaque, transparent=None):
-        op = np.ascontiguousarray(opaque if opaque is not None else [], dtype=RENDER_OBJECT_DTYPE)
-        tr = np.ascontiguousarray(transparent if transparent is not None else [], dtype=RENDER_OBJECT_DTYPE)
+        op, n_op = self._objects(opaque)
+        tr, n_tr = self._objects(transparent)
         st = SvrStats()
-        self.lib.check(self.lib.lib.svr_draw_geometry(self.h, C.byref(scene), op.ctypes.data, op.size,
-                                                      tr.ctypes.data, tr.size, C.byref(st)))
+        self.lib.check(self.lib.lib.svr_draw_geometry(self.h, C.byref(scene), op, n_op, tr, n_tr, C.byref(st)))
         return st
 
     def draw_colored_triangle(self):

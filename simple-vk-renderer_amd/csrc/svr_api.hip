@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include "svr_cull.h"
 #include "svr_launch.h"
 
 using namespace svr;
@@ -331,44 +332,6 @@ int upload_tex_table(SvrContext* ctx, const TexBinding* scratch) {
   HIPCHK(hipStreamSynchronize(ctx->stream));  // host vector dies here
   ctx->tex_slots = n;
   return SVR_OK;
-}
-
-// ---------------------------------------------------------------- is_visible, src/vk_engine.cpp:56-86
-// glm 0.9.9 scalar operation order (glm is an unpinned submodule of the reference), no fma.
-void glm_matmul(const float* a, const float* b, float* out) {
-  for (int j = 0; j < 4; j++)
-    for (int r = 0; r < 4; r++) {
-      float acc = a[0 + r] * b[4 * j + 0];
-      acc = acc + a[4 + r] * b[4 * j + 1];
-      acc = acc + a[8 + r] * b[4 * j + 2];
-      acc = acc + a[12 + r] * b[4 * j + 3];
-      out[4 * j + r] = acc;
-    }
-}
-bool is_visible(const SvrRenderObject& obj, const float* viewproj) {
-  static const float corners[8][3] = {{1, 1, 1},  {1, 1, -1},  {1, -1, 1},  {1, -1, -1},
-                                      {-1, 1, 1}, {-1, 1, -1}, {-1, -1, 1}, {-1, -1, -1}};
-  float m[16];
-  glm_matmul(viewproj, obj.transform, m);
-  float mn[3] = {1.5f, 1.5f, 1.5f}, mx[3] = {-1.5f, -1.5f, -1.5f};
-  for (int c = 0; c < 8; c++) {
-    float p[3];
-    for (int k = 0; k < 3; k++) p[k] = obj.bounds.origin[k] + corners[c][k] * obj.bounds.extents[k];
-    float v[4];
-    for (int r = 0; r < 4; r++) {
-      float add0 = m[0 + r] * p[0] + m[4 + r] * p[1];
-      float add1 = m[8 + r] * p[2] + m[12 + r] * 1.0f;
-      v[r] = add0 + add1;
-    }
-    v[0] = v[0] / v[3];
-    v[1] = v[1] / v[3];
-    v[2] = v[2] / v[3];
-    for (int k = 0; k < 3; k++) {
-      mn[k] = (mn[k] < v[k]) ? mn[k] : v[k];
-      mx[k] = (v[k] < mx[k]) ? mx[k] : v[k];
-    }
-  }
-  return !(mn[2] > 1.f || mx[2] < 0.f || mn[0] > 1.f || mx[0] < -1.f || mn[1] > 1.f || mx[1] < -1.f);
 }
 
 // ---------------------------------------------------------------- pass machinery
