@@ -567,8 +567,6 @@ void run_draw(PassState& ps, const SvrSceneData* scene, const DrawCmd& cmd) {
 }
 
 void run_geometry(PassState& ps, const SvrSceneData* scene, const std::vector<DrawCmd>& cmds) {
-  // (single-threaded also when the rasteriser is not: worked on side by side the draws' lists have to be joined
-  // afterwards, and moving 786 K records costs what the threads saved)
   for (const DrawCmd& cmd : cmds) run_draw(ps, scene, cmd);
 }
 
@@ -653,14 +651,14 @@ inline void store_color(SvrContext* ctx, size_t p, const float c[4]) {
 }
 
 // rasterise rows [y0,y1) of every triangle, in submission order
-// subset (may be null): the indices, ascending, of the triangles that reach rows y0 .. y1 - 1 — the threaded path
-// hands every band its own list; submission order within a pixel is the order of `tris` either way.
+// subset (may be null): the triangles, in submission order, that reach rows y0 .. y1 - 1 — the threaded path hands
+// every band its own list; submission order within a pixel is the order of `tris` either way.
 void raster_rows(SvrContext* ctx, const SvrSceneData* scene, const std::vector<SetupTri>& tris,
-                 int y0, int y1, uint64_t& n_raster, uint64_t& n_shaded, const std::vector<uint32_t>* subset = nullptr) {
+                 int y0, int y1, uint64_t& n_raster, uint64_t& n_shaded, const std::vector<const SetupTri*>* subset = nullptr) {
   uint32_t W = ctx->W;
   const size_t count = subset ? subset->size() : tris.size();
   for (size_t ti = 0; ti < count; ti++) {
-    const SetupTri& t = tris[subset ? (*subset)[ti] : ti];
+    const SetupTri& t = subset ? *(*subset)[ti] : tris[ti];
     int ya = std::max(t.miny, y0), yb = std::min(t.maxy, y1 - 1);
     for (int py = ya; py <= yb; py++) {
       for (int px = t.minx; px <= t.maxx; px++) {
@@ -706,26 +704,55 @@ int run_pass(SvrContext* ctx, const SvrSceneData* scene, const std::vector<DrawC
   ctx->pass_sh = ctx->sh;
   PassState ps;
   ps.ctx = ctx;
-  run_geometry(ps, scene, cmds);
+  const int nthreads = std::max(1, ctx->threads);
+  // Threaded (svr_oracle_set_threads: bench.py's all-core baseline): the draws are set up side by side, each into its own
+  // list with the sequence numbers it has in the one-thread run; nothing is copied together afterwards — the bands of
+  // rows below get lists of pointers in submission order (draw by draw), so every pixel still sees the one-thread order.
+  std::vector<PassState> part;
+  if (nthreads > 1 && cmds.size() > 1) {
+    part.resize(cmds.size());
+    uint32_t key = ps.cur_key;
+    for (size_t i = 0; i < cmds.size(); i++) {
+      part[i].ctx = ctx;
+      part[i].cur_key = key;
+      key += cmds[i].kind == PIPE_COLORED_TRIANGLE ? 1u : cmds[i].index_count / 3;
+    }
+    std::atomic<size_t> next_draw{0};
+    std::vector<std::thread> gpool;
+    for (int ti = 0; ti < nthreads; ti++)
+      gpool.emplace_back([&]() {
+        for (;;) {
+          size_t i = next_draw.fetch_add(1);
+          if (i >= cmds.size()) break;
+          run_draw(part[i], scene, cmds[i]);
+        }
+      });
+    for (auto& th : gpool) th.join();
+    for (const PassState& q : part) ps.binned += q.binned;
+  } else {
+    run_geometry(ps, scene, cmds);
+  }
   // depth loadOp CLEAR 0.0 over the render area = scissor here (src/vk_initializers.cpp:133-147)
   for (uint32_t y = ctx->sy; y < ctx->sy + ctx->sh; y++)
     for (uint32_t x = ctx->sx; x < ctx->sx + ctx->sw; x++) ctx->depth[(size_t)y * ctx->W + x] = 0.0f;
   int y0 = (int)ctx->sy, y1 = (int)(ctx->sy + ctx->sh);
   uint64_t n_raster = 0, n_shaded = 0;
-  int nthreads = std::max(1, ctx->threads);
   if (nthreads == 1) {
     raster_rows(ctx, scene, ps.tris, y0, y1, n_raster, n_shaded);
   } else {
     const int band = 16;
     int nbands = (y1 - y0 + band - 1) / band;
-    // every band's triangles, in submission order (one pass over the list; a band used to walk all of it)
-    std::vector<std::vector<uint32_t>> reach((size_t)nbands);
-    for (size_t i = 0; i < ps.tris.size(); i++) {
-      const SetupTri& t = ps.tris[i];
-      int ya = std::max(t.miny, y0), yb = std::min(t.maxy, y1 - 1);
-      if (ya > yb || t.minx > t.maxx) continue;
-      for (int b = (ya - y0) / band; b <= (yb - y0) / band; b++) reach[(size_t)b].push_back((uint32_t)i);
-    }
+    // every band's triangles, in submission order (one pass over the lists; a band used to walk all of them)
+    std::vector<std::vector<const SetupTri*>> reach((size_t)nbands);
+    auto spread = [&](const std::vector<SetupTri>& list) {
+      for (const SetupTri& t : list) {
+        int ya = std::max(t.miny, y0), yb = std::min(t.maxy, y1 - 1);
+        if (ya > yb || t.minx > t.maxx) continue;
+        for (int b = (ya - y0) / band; b <= (yb - y0) / band; b++) reach[(size_t)b].push_back(&t);
+      }
+    };
+    spread(ps.tris);
+    for (const PassState& q : part) spread(q.tris);
     std::atomic<int> next{0};
     std::vector<uint64_t> nr(nthreads, 0), ns(nthreads, 0);
     std::vector<std::thread> pool;
