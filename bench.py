@@ -114,8 +114,9 @@ def cpu_baseline(args, pkg, shaded_per_frame, sc):
     dt_one = frames(1)
     r.close()
     return {"value": shaded_per_frame / dt_all, "unit": "fragments/s", "cores": cores, "kind": "port",
-            "description": "scalar C++ oracle (-O2, no intrinsics, -ffp-contract=off), forward rasteriser without tiles: geometry on one "
-                           "thread, then 16-row bands over the threads, each walking the triangles that reach it in submission order",
+            "description": "scalar C++ oracle (-O2, no intrinsics, -ffp-contract=off), forward rasteriser without tiles: the draws set up "
+                           "side by side over the threads, then 16-row bands over the threads, each walking the triangles that reach it in "
+                           "submission order",
             "frames_per_s": 1.0 / dt_all,
             "single_thread": {"value": shaded_per_frame / dt_one, "frames_per_s": 1.0 / dt_one, "cores": 1},
             "hardware_concurrency": hw, "cpu_model": model,
