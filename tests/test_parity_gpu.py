@@ -263,6 +263,27 @@ def test_quarters_with_clipped_transparent_triangles(hip, oracle):
         assert_same(a, c, f"camera {k}: quarters vs whole tiles")
 
 
+def test_large_and_small_passes_alternate(hip, oracle):
+    """Stage 1 of a pass of at most 4096 tiles runs on a stream of its own (highest priority, four sets deep), that of a
+    larger pass on the normal one two sets deep: a 3840x2160 context that alternates full frames and row bands — unfenced,
+    each band drawn over what the full frame left (colour LOAD, no clear in between) — ends with the oracle's targets."""
+    def run(lib):
+        r, scene, opaque, transparent = T.setup_sponza(lib, 3840, 2160, lod=8, tex_size=64)
+        r.clear_color((1, 1, 1, 1))
+        for k in range(6):
+            if k % 2 == 0:
+                r.set_scissor(0, 0, 3840, 2160)       # 8160 tiles
+                r.clear_color((0.2 * k, 1.0, 1.0 - 0.1 * k, 1.0))
+            else:
+                r.set_scissor(0, 301 + 97 * k, 3840, 411)  # a band: ~1680 tiles, over the full frame underneath
+            r.draw_geometry(scene, opaque, transparent)
+        out = T._finish(r)
+        r.close()
+        return out
+    a, b = run(hip), run(oracle)
+    assert_same(a, b, "alternating pass sizes", stats=False)
+
+
 def test_split_tiles_change_nothing(hip):
     """SVR_OPT_TUNING bit 3 keeps heavy tiles whole; the quarters of split tiles give the same frame.  (At this size
     the curtain tiles hold hundreds of transparent triangles and the pass's mean load per slot is small: they split.)"""
