@@ -56,7 +56,8 @@ int svr_dist_set_bounds(SvrDist* d, const uint32_t* bounds, size_t count);
 
 /* Collective (every rank, between the same two frames): re-cut the frame into bands of equal cost from the
  * ranks' tile-row costs (svr_get_row_costs), each band's costs scaled to measured_gpu_ms (this rank's GPU time
- * for its band, e.g. SvrStats.gpu_time_ms; <= 0: the cost model alone).  One all-reduce of `height` 64-bit
+ * for its band — SvrStats.tile_ms rather than gpu_time_ms: geometry and binning are the same for every band, and
+ * spread over a band's rows they make a short, dense band look dearer per row than it is; <= 0: the cost model alone).  One all-reduce of `height` 64-bit
  * sums; the cut itself (bottleneck-optimal, integer arithmetic) is computed identically on every rank.
  * *changed (may be NULL) = 1 when the boundaries moved. */
 int svr_dist_rebalance(SvrDist* d, float measured_gpu_ms, int* changed);

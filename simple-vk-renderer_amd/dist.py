@@ -139,7 +139,8 @@ class BandPlan:
 
     def rebalance(self, torch, dist, renderer, device, measured_ms=None):
         """Collective (every rank calls it at the same frame): re-cut the frame from the ranks' latest row costs,
-        each band's costs scaled to its measured GPU time when the caller has one (all ranks or none).
+        each band's costs scaled to its measured GPU time when the caller has one (all ranks or none) — the tile stage's
+        (SvrStats.tile_ms): geometry and binning are the same for every band and would only tilt the rows' costs.
         Returns True when the boundaries changed."""
         if not self.balanced or self.world == 1:
             return False

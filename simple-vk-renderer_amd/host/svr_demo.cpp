@@ -263,7 +263,7 @@ int main(int argc, char** argv) {
         SvrStats st{};
         eng.api.svr_get_stats(eng.ctx, &st);
         int changed = 0;
-        if (svr_dist_rebalance_(dist, st.gpu_time_ms, &changed) != SVR_OK) {
+        if (svr_dist_rebalance_(dist, st.tile_ms, &changed) != SVR_OK) {
           fprintf(stderr, "rank %d: rebalance: %s\n", rank, svr_dist_last_error_());
           return 1;
         }

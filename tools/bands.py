@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--balanced", action="store_true", help="cut the bands by cost (dist.balanced_bounds over svr_get_row_costs of the full frame) instead of equally")
     ap.add_argument("--iterations", type=int, default=4, help="--balanced: re-cuts (each from the bands' modelled rows scaled to their measured time)")
     ap.add_argument("--wall", action="store_true", help="--balanced: scale by the band's wall-clock frame time instead of its GPU time")
+    ap.add_argument("--gpu", action="store_true", help="--balanced: scale by the band's whole GPU time instead of its tile stage's (geometry + binning are the same for every band: spread over its rows they make a short, dense band look dearer per row than it is, and the cut swings)")
     ap.add_argument("--stages", action="store_true", help="also print per-stage kernel times (adds events to the stream)")
     args = ap.parse_args()
     import torch
@@ -60,7 +61,7 @@ def main():
         host_ms = (time.perf_counter() - t0) / args.frames * 1e3  # the host's share: it must stay below the GPU's
         r.sync()
         ms = (time.perf_counter() - t0) / args.frames * 1e3
-        stage, gpu_ms = "", None
+        stage, gpu_ms, tile_ms = "", None, None
         if args.stages or args.balanced:
             r.set_option(A.OPT_KERNEL_TIMING, 2)
             for _ in range(20):
@@ -68,10 +69,11 @@ def main():
             r.sync()
             st = r.get_stats()
             gpu_ms = st.geometry_ms + st.binning_ms + st.tile_ms
+            tile_ms = st.tile_ms
             stage = f" (geometry {st.geometry_ms:.3f} binning {st.binning_ms:.3f} tile {st.tile_ms:.3f})"
         costs, y0c, rowsc = r.row_costs()
         print(f"  N={n} band {rk}: rows {y0}..{y0 + rows}: {ms:.4f} ms/frame (host enqueue {host_ms:.4f}){stage}", flush=True)
-        return ms, gpu_ms, pkg.dist.BandPlan.spread(costs, y0c, rowsc, H)
+        return ms, (gpu_ms if args.gpu else tile_ms), pkg.dist.BandPlan.spread(costs, y0c, rowsc, H)
 
     base = None
     for n in (1, 2, 4, 8):
