@@ -198,8 +198,8 @@ __device__ __forceinline__ float plane_dist(int plane, const float* c) {
 }
 
 // Sutherland-Hodgman against the six planes (C2); new vertices always interpolate inside -> outside.
-__device__ int clip_polygon(VOut* poly, int n) {
-  VOut tmp[12];
+// poly, tmp: room for 12 vertices each (LDS in clip_kernel: indexed by run-time values they would otherwise live in scratch)
+__device__ int clip_polygon(VOut* poly, VOut* tmp, int n) {
   for (int plane = 0; plane < 6 && n >= 3; plane++) {
     int m = 0;
     for (int i = 0; i < n; i++) {
@@ -225,18 +225,27 @@ __device__ int clip_polygon(VOut* poly, int n) {
   return n >= 3 ? n : 0;
 }
 
-// One lane per queued triangle, grid-stride over the device-side queue length.
+// One lane per queued triangle, grid-stride over the device-side queue length; CLIP_LANES lanes of the wave work.
+// The polygon under the knife is indexed by run-time values: as a local array it lives in scratch memory, and a kernel
+// with a scratch frame pays ~2.5 us at every dispatch (tools/gapbench.hip) — on the chain that bounds small passes.
+// It lives in LDS instead, 1152 bytes per working lane (eight lanes: with more LDS per workgroup than 10 KiB the compiler drops the
+// 128-VGPR cap of __launch_bounds__(64, 4), and a stage-1 wave above 128 waits for two tile-kernel waves to retire); the queue
+// holds a few hundred triangles per frame.
+constexpr uint32_t CLIP_LANES = 8;
 __global__ __launch_bounds__(64, 4) void clip_kernel(FrameParams P) {
+  __shared__ VOut s_poly[CLIP_LANES][12];
+  __shared__ VOut s_tmp[CLIP_LANES][12];
   // the setup kernel is complete (stream order): freeze the length of its part of the pair list
   if (blockIdx.x == 0 && threadIdx.x == 0) P.counters->n_pairs_setup = min(P.counters->n_pairs, P.bin_cap);
+  if (threadIdx.x >= CLIP_LANES) return;
   uint32_t n = min(P.counters->n_clip, P.clip_cap);
   float hw = (float)P.W * 0.5f, hh = (float)P.H * 0.5f;
-  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+  VOut* poly = s_poly[threadIdx.x];
+  for (uint32_t q = blockIdx.x * CLIP_LANES + threadIdx.x; q < n; q += gridDim.x * CLIP_LANES) {
     ClipItem it = P.clip_queue[q];
     const DrawDesc& d = P.draws[it.draw];
     uint32_t kind = (d.flags >> F_KIND_SHIFT) & 3u;
     uint32_t seq = d.tri_base + it.tri;
-    VOut poly[12];
     if (kind == PIPE_COLORED_TRIANGLE) {
       colored_triangle_vert(0, poly[0]);
       colored_triangle_vert(1, poly[1]);
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(64, 4) void clip_kernel(FrameParams P) {
     } else {
       for (int k = 0; k < 3; k++) shade_corner(d, kind, d.mvp, d.idx[3 * it.tri + k], poly[k]);
     }
-    int np = clip_polygon(poly, 3);
+    int np = clip_polygon(poly, s_tmp[threadIdx.x], 3);
     if (np < 3) continue;
     // The fan's records are one contiguous block, and the parent's (invalid) main slot links to it:
     // the tile kernel's visibility pass keeps only (depth, key) per pixel and (key >> 2) - 1 names the main
@@ -261,11 +270,10 @@ __global__ __launch_bounds__(64, 4) void clip_kernel(FrameParams P) {
               s2 = to_screen(poly[i + 1].clip, hw, hh);
       if (!(s0.ok && s1.ok && s2.ok)) continue;
       if (!(poly[0].clip[3] > 0.0f && poly[i].clip[3] > 0.0f && poly[i + 1].clip[3] > 0.0f)) continue;
-      uint4 piece[16];
-      if (!setup_triangle(P, &poly[0], &poly[i], &poly[i + 1], s0, s1, s2, make_key(seq, d.flags, P.tex[d.tex], true), d.flags, P.tex[d.tex], piece, nullptr)) continue;
+      // the record is written where it goes (no staging in registers: sixteen more live uint4 put the kernel over its
+      // register cap); a piece that turns out degenerate leaves a slot that the next one, or store_invalid below, overwrites
       uint4* dst = reinterpret_cast<uint4*>(P.recs + P.n_tris + first + used);
-#pragma unroll
-      for (int k = 0; k < 16; k++) dst[k] = piece[k];
+      if (!setup_triangle(P, &poly[0], &poly[i], &poly[i + 1], s0, s1, s2, make_key(seq, d.flags, P.tex[d.tex], true), d.flags, P.tex[d.tex], *reinterpret_cast<uint4(*)[16]>(dst), nullptr)) continue;
       used++;
       if (P.instrument) atomicAdd(&P.counters->binned, 1ull);
     }

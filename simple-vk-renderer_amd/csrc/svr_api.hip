@@ -425,7 +425,25 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   // such a pass is bounded by stage 1 — its setup kernel finds the CUs taken by the tile kernel's first, longest
   // workgroups (21 us alone, 53 us beside it) — and with priority its workgroups get the slots that come free
   // (1080p: -5 % per frame).  A 4K frame is bounded by its tile kernel and loses 0.8 % to the same favour.
-  hipStream_t s = ctx->stream, g = pipe ? (P.n_tiles <= SPLIT_TILES_MAX ? ctx->gstream_hi : ctx->gstream) : ctx->stream;
+  // Either stream is made when a pass first needs it: the runtime maps a process's streams onto a handful of hardware
+  // queues (four by default), and streams that share one serialise — a context that only ever renders one size of pass
+  // must not take a queue it never uses (two contexts with both streams in one process: stage 1 and the tile kernel of
+  // the second ended up in ONE queue, 0.093 -> 0.27 ms per 1080p frame).
+  hipStream_t s = ctx->stream, g = ctx->stream;
+  if (pipe) {
+    const bool hi = P.n_tiles <= SPLIT_TILES_MAX;
+    hipStream_t& slot = hi ? ctx->gstream_hi : ctx->gstream;
+    if (!slot) {
+      if (hi) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        HIPCHK(hipStreamCreateWithPriority(&slot, hipStreamNonBlocking, greatest));
+      } else {
+        HIPCHK(hipStreamCreateWithFlags(&slot, hipStreamNonBlocking));
+      }
+    }
+    g = slot;
+  }
   if (pipe) {
     if (ctx->last_g && ctx->last_g != g) {  // keep stage 1 of consecutive passes in order across the two streams
       HIPCHK(hipEventRecord(ctx->ev_gswitch, ctx->last_g));
@@ -566,8 +584,8 @@ int submit_clear(SvrContext* ctx, const SvrContext::LoggedOp& op) {  // every lo
 
 int recover_from_overflow(SvrContext* ctx) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->gstream));
-  HIPCHK(hipStreamSynchronize(ctx->gstream_hi));
+  if (ctx->gstream) HIPCHK(hipStreamSynchronize(ctx->gstream));
+  if (ctx->gstream_hi) HIPCHK(hipStreamSynchronize(ctx->gstream_hi));
   const uint32_t failed_seq = *(volatile uint32_t*)ctx->h_failed_seq;
   *ctx->h_failed_seq = 0;
   for (SvrContext::LoggedOp& op : ctx->log) {
@@ -897,15 +915,8 @@ int svr_create(const SvrConfig* cfg, SvrContext** out) {
   if ((r = hipMemset(ctx->depth_own, 0, n * 4)) != hipSuccess) return bail(r, "hipMemset(depth)");
   ctx->color = ctx->color_own;
   ctx->depth = ctx->depth_own;
-  // (A high-priority stream was tried for stage 1 and changes nothing: the workgroup dispatcher keeps
-  // feeding the tile kernel that is already running, whatever the queue priority.)
-  if ((r = hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking)) != hipSuccess) return bail(r, "hipStreamCreate");
-  {
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if ((r = hipStreamCreateWithPriority(&ctx->gstream_hi, hipStreamNonBlocking, greatest)) != hipSuccess) return bail(r, "hipStreamCreate");
-    if ((r = hipEventCreateWithFlags(&ctx->ev_gswitch, hipEventDisableTiming)) != hipSuccess) return bail(r, "hipEventCreate");
-  }
+  // (the internal streams are made by the first pass that needs them: submit_pass)
+  if ((r = hipEventCreateWithFlags(&ctx->ev_gswitch, hipEventDisableTiming)) != hipSuccess) return bail(r, "hipEventCreate");
   for (int i = 0; i < SvrContext::NSETS; i++) {
     if ((r = hipEventCreateWithFlags(&ctx->sets[i].ev_bin, hipEventDisableTiming)) != hipSuccess) return bail(r, "hipEventCreate");
   }
