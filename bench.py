@@ -28,6 +28,12 @@ import os
 import sys
 import time
 
+# The HIP runtime maps a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and streams that
+# share one run their work in order.  A rank uses the caller's stream, the library's stage-1 stream and what the
+# collective library creates: give them room, so that stage 1 never shares a queue with the tile kernel it should overlap
+# (set before the runtime starts; an operator's own setting wins).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
