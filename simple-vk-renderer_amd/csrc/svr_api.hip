@@ -437,7 +437,11 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
       if (hi) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        HIPCHK(hipStreamCreateWithPriority(&slot, hipStreamNonBlocking, greatest));
+        if (hipStreamCreateWithPriority(&slot, hipStreamNonBlocking, greatest) != hipSuccess) {
+          (void)hipGetLastError();  // no priorities here: an ordinary stream does the job, a little later
+          slot = nullptr;
+          HIPCHK(hipStreamCreateWithFlags(&slot, hipStreamNonBlocking));
+        }
       } else {
         HIPCHK(hipStreamCreateWithFlags(&slot, hipStreamNonBlocking));
       }
