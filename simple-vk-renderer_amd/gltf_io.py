@@ -249,6 +249,9 @@ def load_gltf(path):
     linear one (src/vk_engine.cpp:231-261)."""
     from . import glmath, scenes
     doc, buffers, uri_bytes = _read_container(path)
+    for e in doc.get("extensionsRequired", []):  # the reference's parser knows three (src/vk_loader.cpp:169-173) and refuses the rest
+        if e not in ("KHR_mesh_quantization", "KHR_texture_transform", "KHR_materials_variants"):
+            raise ValueError(f"required extension {e} is not supported")
     sc = scenes.Scene()
     TRI = dict(min_lod=0.0, max_lod=1000.0)
     nearest, linear = (9728, 9984, 9986), None

@@ -316,6 +316,14 @@ std::shared_ptr<LoadedScene> load_gltf_meshes(SvrEngine* engine, const std::stri
     return std::shared_ptr<LoadedScene>();
   };
 
+  // The reference's parser is built for three extensions (src/vk_loader.cpp:169-173); fastgltf refuses a file that
+  // REQUIRES any other one (Draco, meshopt, basisu ...: data this loader could not read either).
+  for (size_t i = 0; i < gltf["extensionsRequired"].size(); i++) {
+    const std::string& e = gltf["extensionsRequired"][i].str;
+    if (e != "KHR_mesh_quantization" && e != "KHR_texture_transform" && e != "KHR_materials_variants")
+      return fail("required extension " + e + " is not supported");
+  }
+
   // samplers
   for (size_t i = 0; i < gltf["samplers"].size(); i++) {
     const Value& s = gltf["samplers"][i];

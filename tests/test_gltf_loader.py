@@ -404,7 +404,10 @@ def test_gltf_loader_rejects_broken_files(tmp_path, oracle):
     subprocess.run(["make", "-s"], cwd=HOST_DIR, check=True)
     exe = os.path.join(HOST_DIR, "svr_demo")
     cases = {"notjson.gltf": b"{ this is not json", "empty.glb": b"glTF\x02\x00\x00\x00\x0c\x00\x00\x00",
-             "badacc.gltf": json.dumps({"asset": {"version": "2.0"}, "meshes": [{"primitives": [{"attributes": {"POSITION": 3}}]}]}).encode()}
+             "badacc.gltf": json.dumps({"asset": {"version": "2.0"}, "meshes": [{"primitives": [{"attributes": {"POSITION": 3}}]}]}).encode(),
+             # fastgltf is built for three extensions in the reference (src/vk_loader.cpp:169-173) and refuses files that require others
+             "draco.gltf": json.dumps({"asset": {"version": "2.0"}, "extensionsRequired": ["KHR_draco_mesh_compression"],
+                                       "extensionsUsed": ["KHR_draco_mesh_compression"]}).encode()}
     for name, body in cases.items():
         p = tmp_path / name
         p.write_bytes(body)
@@ -495,3 +498,64 @@ def test_loader_decodes_the_minor_formats(tmp_path, oracle, fmt):
     assert "failed to load texture" not in b["log"] and "25 images" in b["log"]
     T.assert_images_identical(a["color"], b["color"], f"{fmt} textures colour")
     T.assert_images_identical(a["depth"], b["depth"], f"{fmt} textures depth")
+
+
+def test_quantized_attributes_load_like_their_float_twins(tmp_path, oracle):
+    """KHR_mesh_quantization (one of the three extensions the reference's parser is built for, src/vk_loader.cpp:169):
+    SHORT positions, normalized BYTE normals, normalized UNSIGNED_SHORT texture coordinates and UNSIGNED_BYTE colours.  The
+    file that requires the extension renders the very frame of its twin with the same values as floats — through the C++
+    loader and through the Python one."""
+    pos16 = np.int16([[-300, 0, 0], [300, 0, 0], [0, 450, 0], [-300, 0, 200], [0, 450, 200], [300, 0, 200]])
+    nrm8 = np.int8([[0, 0, 127], [0, 0, 127], [0, 0, 127], [0, 127, 0], [-128, 0, 0], [0, -127, 0]])
+    uv16 = np.uint16([[0, 0], [65535, 0], [32768, 65535], [0, 13107], [13107, 13107], [52428, 0]])
+    col8 = np.uint8([[255, 0, 0, 255], [0, 255, 0, 255], [0, 0, 255, 255], [255, 255, 0, 128], [0, 255, 255, 255], [51, 102, 204, 255]])
+    as_float = {"POSITION": pos16.astype(np.float32), "NORMAL": np.maximum(nrm8.astype(np.float32) / np.float32(127.0), np.float32(-1.0)),
+                "TEXCOORD_0": uv16.astype(np.float32) / np.float32(65535.0), "COLOR_0": col8.astype(np.float32) / np.float32(255.0)}
+
+    def pad(raw):  # elements of quantized accessors must start on 4-byte boundaries: pad every element row
+        return raw
+
+    def write(name, quantized):
+        bin_, views, accs = bytearray(), [], []
+
+        def add(raw, ctype, gtype, count, normalized=False, stride=None):
+            while len(bin_) % 4:
+                bin_.append(0)
+            v = {"buffer": 0, "byteOffset": len(bin_), "byteLength": len(raw)}
+            if stride:
+                v["byteStride"] = stride
+            bin_.extend(raw)
+            views.append(v)
+            a = {"bufferView": len(views) - 1, "componentType": ctype, "count": count, "type": gtype}
+            if normalized:
+                a["normalized"] = True
+            accs.append(a)
+            return len(accs) - 1
+
+        if quantized:
+            p4 = np.zeros((6, 4), np.int16); p4[:, :3] = pos16   # 6-byte elements padded to a stride of 8
+            n4 = np.zeros((6, 4), np.int8); n4[:, :3] = nrm8     # 3-byte elements padded to a stride of 4
+            attrs = {"POSITION": add(p4.tobytes(), 5122, "VEC3", 6, stride=8), "NORMAL": add(n4.tobytes(), 5120, "VEC3", 6, True, stride=4),
+                     "TEXCOORD_0": add(uv16.tobytes(), 5123, "VEC2", 6, True), "COLOR_0": add(col8.tobytes(), 5121, "VEC4", 6, True)}
+        else:
+            attrs = {k: add(v.astype(np.float32).tobytes(), 5126, {2: "VEC2", 3: "VEC3", 4: "VEC4"}[v.shape[1]], 6) for k, v in as_float.items()}
+        doc = {"asset": {"version": "2.0"}, "bufferViews": views, "accessors": accs,
+               "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [1.0, 1.0, 1.0, 1.0]}}],
+               "meshes": [{"primitives": [{"attributes": attrs, "material": 0}]}],
+               "nodes": [{"mesh": 0, "translation": [0, -1.5, -9], "scale": [0.01, 0.01, 0.01]}], "scenes": [{"nodes": [0]}], "scene": 0,
+               "buffers": [{"byteLength": len(bin_), "uri": "data:application/octet-stream;base64," + base64.b64encode(bytes(bin_)).decode()}]}
+        if quantized:
+            doc["extensionsUsed"] = doc["extensionsRequired"] = ["KHR_mesh_quantization"]
+        path = str(tmp_path / name)
+        with open(path, "w") as f:
+            json.dump(doc, f)
+        return path
+
+    cam = (0.0, 0.0, 0.0, 0.0, 0.0)
+    q, f = write("quant.gltf", True), write("float.gltf", False)
+    a, b = run_demo(oracle.path, q, str(tmp_path / "q"), cam), run_demo(oracle.path, f, str(tmp_path / "f"), cam)
+    assert (a["depth"] > 0).sum() > 500, "the mesh should be in view"
+    T.assert_images_identical(a["color"], b["color"], "quantized vs float colour")
+    T.assert_images_identical(a["depth"], b["depth"], "quantized vs float depth")
+    sq, sf = IO.load_gltf(q), IO.load_gltf(f)
+    assert np.array_equal(sq.meshes[0].vertices, sf.meshes[0].vertices)
