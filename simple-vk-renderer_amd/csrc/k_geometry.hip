@@ -76,17 +76,21 @@ __global__ __launch_bounds__(256, 4) void setup_kernel(FrameParams P) {
   // Whole chunks that cannot reach the scissor — outside the frustum, or (a rank of the multi-GPU path renders a
   // band of rows) above or below the band — are dropped before a single index is fetched: the box of the chunk's
   // vertices comes from the mesh's index-group table (svr_upload_mesh).
+  uint32_t v_first = 0, v_count = 0;  // wave-uniform
   if (live && d.groups && kind != PIPE_COLORED_TRIANGLE) {
     const uint32_t first = d.first_index + 3u * ch.first_tri, last = first + 3u * min(64u, d.tri_count - ch.first_tri) - 1u;
     typedef const __attribute__((address_space(4))) float* const_floats;
-    const_floats g0 = (const_floats)(const void*)(d.groups + 6u * (first / GROUP_INDICES));
-    const_floats g1 = (const_floats)(const void*)(d.groups + 6u * (last / GROUP_INDICES));
+    const_floats g0 = (const_floats)(const void*)(d.groups + GROUP_WORDS * (first / GROUP_INDICES));
+    const_floats g1 = (const_floats)(const void*)(d.groups + GROUP_WORDS * (last / GROUP_INDICES));
     float a[6], b[6], lo[3], hi[3];
 #pragma unroll
     for (int k = 0; k < 6; k++) {  // both boxes in one round of scalar loads
       a[k] = g0[k];
       b[k] = g1[k];
     }
+    // ... and, with them, the range of vertices the chunk's indices name
+    v_first = min(f2u(g0[6]), f2u(g1[6]));
+    v_count = max(f2u(g0[7]), f2u(g1[7])) - v_first + 1u;
     bool boxes_ok = true;  // a box with a non-finite vertex behind it is stored as NaNs: never culled
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -100,6 +104,29 @@ __global__ __launch_bounds__(256, 4) void setup_kernel(FrameParams P) {
   uint32_t seq = d.tri_base + tri;
   __shared__ uint32_t s_tot[8];
   __shared__ uint4 s_tr[4][64 * 8];  // per wave: one half (8 pieces) of its 64 records, for the transposed store
+  // The chunk's vertices through LDS.  Its 192 indices name a short run of the vertex buffer (a mesh's triangles
+  // are laid out near their vertices), known from the group table before a single index has arrived: the wave reads
+  // that run as it lies — consecutive lanes consecutive 48-byte vertices, 3 KiB per instruction, in flight TOGETHER
+  // with the index fetch instead of behind it — runs mesh.vert once per vertex (two rounds of 64 at most, where the
+  // three corners of 64 triangles were three), and parks the results in the wave's (still idle) transposition
+  // buffer, where the triangles pick their corners up.  A chunk whose run is longer than STAGE_VERTS gathers as before.
+  constexpr uint32_t STAGE_VERTS = 128;
+  static_assert(STAGE_VERTS * sizeof(VOut) <= 64 * 8 * sizeof(uint4), "staged vertices fit the wave's transposition buffer");
+  const uint32_t wave_in_group = threadIdx.x >> 6;
+  VOut* s_v = reinterpret_cast<VOut*>(s_tr[wave_in_group]);
+  const bool staged = live && v_count != 0u && v_count <= STAGE_VERTS && kind != PIPE_COLORED_TRIANGLE;  // wave-uniform
+  if (staged) {
+#pragma unroll
+    for (uint32_t r = 0; r < STAGE_VERTS / 64u; r++) {
+      const uint32_t j = r * 64u + lane;
+      if (j < v_count) {
+        VOut o;
+        shade_corner(d, kind, d.mvp, v_first + j, o);
+        s_v[j] = o;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the wave's own LDS traffic is in order; this keeps the compiler from moving it
+  }
   uint4 piece[16];
   piece[0] = make_uint4(1u, 0u, 0u, 0u);  // the invalid record: minx = 1 > maxx = 0
   TriGeom g{};
@@ -113,9 +140,15 @@ __global__ __launch_bounds__(256, 4) void setup_kernel(FrameParams P) {
     } else {
       const float* mvp = d.mvp;  // sceneData.viewproj * PushConstants.renderMatrix, computed once per draw
       uint32_t i0 = d.idx[3 * tri + 0], i1 = d.idx[3 * tri + 1], i2 = d.idx[3 * tri + 2];
-      shade_corner(d, kind, mvp, i0, v0);
-      shade_corner(d, kind, mvp, i1, v1);
-      shade_corner(d, kind, mvp, i2, v2);
+      if (staged) {
+        v0 = s_v[i0 - v_first];
+        v1 = s_v[i1 - v_first];
+        v2 = s_v[i2 - v_first];
+      } else {
+        shade_corner(d, kind, mvp, i0, v0);
+        shade_corner(d, kind, mvp, i1, v1);
+        shade_corner(d, kind, mvp, i2, v2);
+      }
     }
     int c0 = outcode(v0.clip), c1 = outcode(v1.clip), c2 = outcode(v2.clip);
     bool to_clip = false;

@@ -1034,11 +1034,14 @@ int svr_upload_mesh(SvrContext* ctx, const uint32_t* indices, size_t n_indices, 
   // src/vk_loader.cpp:366-375, over all vertices of the mesh so far — and only is_visible may trust them.)
   {
     const size_t n_groups = (n_indices + GROUP_INDICES - 1) / GROUP_INDICES;
-    std::vector<float> boxes(std::max<size_t>(n_groups, 1) * 6);
+    std::vector<float> boxes(std::max<size_t>(n_groups, 1) * GROUP_WORDS);
     for (size_t g = 0; g < n_groups; g++) {
       float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      uint32_t vmin = 0xffffffffu, vmax = 0u;  // the vertices the group names: the setup kernel stages that range through LDS
       const size_t end = std::min(n_indices, (g + 1) * GROUP_INDICES);
       for (size_t i = g * GROUP_INDICES; i < end; i++) {
+        vmin = std::min(vmin, indices[i]);
+        vmax = std::max(vmax, indices[i]);
         const float* p = vertices[indices[i]].position;
         for (int k = 0; k < 3; k++) {
           lo[k] = p[k] < lo[k] ? p[k] : lo[k];
@@ -1047,9 +1050,11 @@ int svr_upload_mesh(SvrContext* ctx, const uint32_t* indices, size_t n_indices, 
         }
       }
       for (int k = 0; k < 3; k++) {
-        boxes[g * 6 + k] = lo[k];
-        boxes[g * 6 + 3 + k] = hi[k];
+        boxes[g * GROUP_WORDS + k] = lo[k];
+        boxes[g * GROUP_WORDS + 3 + k] = hi[k];
       }
+      std::memcpy(&boxes[g * GROUP_WORDS + 6], &vmin, 4);
+      std::memcpy(&boxes[g * GROUP_WORDS + 7], &vmax, 4);
     }
     hipError_t rg = hipMalloc((void**)&m.groups, boxes.size() * sizeof(float));
     if (rg == hipSuccess) rg = hipMemcpy(m.groups, boxes.data(), boxes.size() * sizeof(float), hipMemcpyHostToDevice);

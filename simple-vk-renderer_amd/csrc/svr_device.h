@@ -62,13 +62,14 @@ struct DrawDesc {
   uint32_t tri_base;        // sequence number of the draw's first triangle (submission order)
   uint32_t tex;             // TexBinding index
   uint32_t flags;           // kind << F_KIND_SHIFT | F_TRANSPARENT
-  const float* groups;      // the mesh's index-group boxes (svr_upload_mesh): float[6] = min xyz, max xyz of the vertices
+  const float* groups;      // the mesh's index-group table (svr_upload_mesh): GROUP_WORDS words per group = float[6] min xyz, max xyz of the vertices
                             // named by indices [192 g, 192 g + 192); NULL = none (the wave chunks are never skipped)
   uint32_t first_index;     // the draw's offset in the mesh's index buffer: locates its chunks' groups
   uint32_t pad;
 };
 static_assert(sizeof(DrawDesc) == 192 && offsetof(DrawDesc, vtx) == 144 && offsetof(DrawDesc, groups) == 176, "DrawDesc layout");
 constexpr uint32_t GROUP_INDICES = 192;  // 64 triangles
+constexpr uint32_t GROUP_WORDS = 8;      // a group's entry: float[6] box of the vertices its indices name, then their lowest and highest vertex index (uint32)
 
 // 64 consecutive triangles of one draw: the unit of work of one wave of the setup kernel.
 struct WaveChunk {
