@@ -284,6 +284,43 @@ def test_large_and_small_passes_alternate(hip, oracle):
     assert_same(a, b, "alternating pass sizes", stats=False)
 
 
+def test_vertex_runs_of_every_length(hip, oracle):
+    """The setup kernel reads a chunk's vertices as one run of the vertex buffer when its 192 indices name at most 128
+    consecutive vertices, and gathers them per corner otherwise.  The atrium with the triangles of every surface shuffled —
+    wholly (runs of thousands: the gather path) and within windows of 48 and 90 triangles (runs around the limit) — is still
+    the oracle's frame (the shuffle changes submission order, for both alike)."""
+    import copy
+    pkg = g.load_package()
+    S = pkg.scenes
+    for window in (0, 48, 90):
+        sc = copy.deepcopy(T.sponza_scene(8, 64))
+        rng = np.random.default_rng(100 + window)
+        for mesh in sc.meshes:
+            idx = mesh.indices.copy()
+            for sf in mesh.surfaces:
+                tris = idx[sf.start_index:sf.start_index + sf.count].reshape(-1, 3)
+                n = tris.shape[0]
+                if window == 0:
+                    tris[:] = tris[rng.permutation(n)]
+                else:
+                    for a in range(0, n, window):
+                        b = min(n, a + window)
+                        tris[a:b] = tris[a + rng.permutation(b - a)]
+            mesh.indices = idx
+        frames = []
+        for lib in (hip, oracle):
+            r = lib.create(640, 360)
+            handles = sc.upload(r)
+            opaque, transparent = sc.render_objects(handles)
+            scene = S.scene_data_struct(*S.config3_camera(), 640, 360)
+            r.set_option(1, 1)
+            r.clear_color((1, 1, 1, 1))
+            r.draw_geometry(scene, opaque, transparent)
+            frames.append(T._finish(r))
+            r.close()
+        assert_same(frames[0], frames[1], f"triangles shuffled in windows of {window}")
+
+
 def test_split_tiles_change_nothing(hip):
     """SVR_OPT_TUNING bit 3 keeps heavy tiles whole; the quarters of split tiles give the same frame.  (At this size
     the curtain tiles hold hundreds of transparent triangles and the pass's mean load per slot is small: they split.)"""
