@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--gather-fp16", action="store_true", help="N > 1: all-gather the RGBA16F target instead of the swapchain image")
     ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=25, help="repetitions of the timed --steps block (the median block is reported)")
-    ap.add_argument("--profile-tag", default="r02_h", help="profiles/<tag>_traffic.json and <tag>_valu.json of this build are quoted in the line")
+    ap.add_argument("--profile-tag", default="r02_i", help="profiles/<tag>_traffic.json and <tag>_valu.json of this build are quoted in the line")
     return ap.parse_args()
 
 
