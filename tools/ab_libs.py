@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--frames", type=int, default=40)
     ap.add_argument("--tuning", type=int, default=0)
     ap.add_argument("--stages", action="store_true")
+    ap.add_argument("--stream", action="store_true", help="render on a stream of its own (torch.cuda.Stream) instead of the null stream")
     ap.add_argument("--band", default="", help="y0,rows: render only these rows (scissor), as one rank of a sharded frame does")
     args = ap.parse_args()
     pkg = g.load_package()
@@ -35,7 +36,7 @@ def main():
     pos, pitch, yaw = S.config5_camera() if args.instances == 16 else S.config3_camera()
     scene = S.scene_data_struct(pos, pitch, yaw, args.width, args.height)
     inst = S.config5_instances() if args.instances == 16 else None
-    ctx = []
+    ctx, keep = [], []
     for spec in args.libs:  # path[:tuning]
         path, _, tun = spec.partition(":")
         lib = A.SvrLib(os.path.abspath(path))
@@ -43,6 +44,10 @@ def main():
         handles = sc.upload(r)
         opaque, transparent = sc.render_objects(handles, instance_transforms=inst)
         r.set_option(A.OPT_TUNING, int(tun) if tun else args.tuning)
+        if args.stream:
+            st = torch.cuda.Stream()
+            keep.append(st)
+            r.set_stream(st.cuda_stream)
         if args.band:
             y0, rows = (int(v) for v in args.band.split(","))
             r.set_scissor(0, y0, args.width, rows)
