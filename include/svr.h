@@ -242,6 +242,16 @@ int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint
                       const float world[16], const SvrSceneData* scene, SvrMaterial material,
                       float* out_clip, float* out_varyings);
 
+/* The other two vertex programs as stand-alone operators (same purpose as svr_run_mesh_vert):
+ *   SVR_VS_COLORED_TRIANGLE       shaders/colored_triangle.vert:6-25: gl_VertexIndex = first_vertex + i (at most 3
+ *                                 vertices; mesh and render_matrix are ignored and may be 0 / NULL)
+ *   SVR_VS_COLORED_TRIANGLE_MESH  shaders/colored_triangle_mesh.vert:28-38: gl_Position = render_matrix * vec4(position, 1)
+ * out_clip: 4 floats per vertex; out_varyings: 8 floats per vertex laid out like mesh.vert's (the three normal slots
+ * are 0: these programs have no such output; then color.xyz, uv.xy). */
+enum SvrVertexShader { SVR_VS_COLORED_TRIANGLE = 1, SVR_VS_COLORED_TRIANGLE_MESH = 2 };
+int svr_run_vertex_shader(SvrContext* ctx, int shader, SvrMesh mesh, uint32_t first_vertex, uint32_t n_vertices,
+                          const float render_matrix[16], float* out_clip, float* out_varyings);
+
 /* Implementation switches (the reference has compile-time flags only).
  * SVR_OPT_COUNT_FRAGMENTS: 1 = count rasterized/shaded fragments and binned triangles with device
  * atomics (instrumented kernels; keep 0 for timed runs).

@@ -1271,6 +1271,31 @@ int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint
   return SVR_OK;
 }
 
+int svr_run_vertex_shader(SvrContext* ctx, int shader, SvrMesh mesh, uint32_t first_vertex, uint32_t n_vertices,
+                          const float render_matrix[16], float* out_clip, float* out_varyings) {
+  if (!ctx || !out_clip || !out_varyings) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_run_vertex_shader: null argument");
+  const Mesh* m = nullptr;
+  if (shader == SVR_VS_COLORED_TRIANGLE) {
+    if ((uint64_t)first_vertex + n_vertices > 3) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_run_vertex_shader: colored_triangle.vert has 3 vertices");
+  } else if (shader == SVR_VS_COLORED_TRIANGLE_MESH) {
+    if (!render_matrix) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_run_vertex_shader: null matrix");
+    m = get_mesh(ctx, mesh);
+    if (!m) return fail(SVR_ERR_BAD_HANDLE, "svr_run_vertex_shader: bad mesh");
+    if ((uint64_t)first_vertex + n_vertices > m->vtx.size())
+      return fail(SVR_ERR_INVALID_ARGUMENT, "svr_run_vertex_shader: vertex range outside the mesh");
+  } else {
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_run_vertex_shader: unknown shader");
+  }
+  for (uint32_t i = 0; i < n_vertices; i++) {
+    VOut o;
+    if (m) colored_triangle_mesh_vert(m->vtx[first_vertex + i], render_matrix, o);
+    else colored_triangle_vert((int)(first_vertex + i), o);
+    std::memcpy(out_clip + 4 * (size_t)i, o.clip, 16);
+    std::memcpy(out_varyings + 8 * (size_t)i, o.attr, 32);
+  }
+  return SVR_OK;
+}
+
 int svr_set_option(SvrContext* ctx, int option, int64_t) {
   if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
   if (option != SVR_OPT_COUNT_FRAGMENTS && option != SVR_OPT_KERNEL_TIMING && option != SVR_OPT_TILE_CYCLES &&

@@ -72,6 +72,7 @@ OPT_TUNING = 4
 OPT_QUEUE_CAPS = 5
 OPT_DEVICE_FLATTEN = 6
 BACKGROUND_GRADIENT, BACKGROUND_SKY = 0, 1
+VS_COLORED_TRIANGLE, VS_COLORED_TRIANGLE_MESH = 1, 2
 SWAPCHAIN_B8G8R8A8, SWAPCHAIN_R8G8B8A8 = 0, 1
 GRADIENT_DEFAULT = (1.0, 1.0, 1.0, 1.0) * 2 + (0.0,) * 8       # src/vk_engine.cpp:981-982
 SKY_DEFAULT = (0.1, 0.2, 0.4, 0.97) + (0.0,) * 12               # src/vk_engine.cpp:988
@@ -82,7 +83,7 @@ SYMBOLS = ["svr_create", "svr_destroy", "svr_set_stream", "svr_bind_targets", "s
            "svr_read_image_level", "svr_create_sampler", "svr_write_material", "svr_clear_color",
            "svr_draw_background", "svr_copy_to_swapchain", "svr_read_swapchain",
            "svr_set_scissor", "svr_draw_geometry", "svr_draw_colored_triangle", "svr_draw_tex_image",
-           "svr_run_mesh_vert", "svr_set_option", "svr_debug_trace_pixel", "svr_debug_read_trace", "svr_debug_read_bins", "svr_debug_read_tile_cycles", "svr_debug_rcp_sweep", "svr_get_row_costs", "svr_sync", "svr_read_color", "svr_read_depth", "svr_get_stats",
+           "svr_run_mesh_vert", "svr_run_vertex_shader", "svr_set_option", "svr_debug_trace_pixel", "svr_debug_read_trace", "svr_debug_read_bins", "svr_debug_read_tile_cycles", "svr_debug_rcp_sweep", "svr_get_row_costs", "svr_sync", "svr_read_color", "svr_read_depth", "svr_get_stats",
            "svr_last_error", "svr_backend_name"]
 
 
@@ -131,6 +132,8 @@ class SvrLib:
                                          C.c_uint32, C.c_uint32, C.POINTER(SvrStats)]
         L.svr_run_mesh_vert.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
                                         C.POINTER(SvrSceneData), C.c_uint32, P, P]
+        if hasattr(L, "svr_run_vertex_shader"):  # tools/ab_libs.py also loads builds that predate it
+            L.svr_run_vertex_shader.argtypes = [P, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), P, P]
         L.svr_set_option.argtypes = [P, C.c_int, C.c_int64]
         L.svr_debug_trace_pixel.argtypes = [P, C.c_int, C.c_int]
         L.svr_debug_read_trace.argtypes = [P, P]
@@ -321,6 +324,15 @@ class Renderer:
         self.lib.check(self.lib.lib.svr_run_mesh_vert(self.h, mesh, first_vertex, n_vertices, _f16m(world),
                                                       C.byref(scene), material, clip.ctypes.data,
                                                       var.ctypes.data))
+        return clip, var
+
+    def run_vertex_shader(self, shader, mesh=0, first_vertex=0, n_vertices=3, render_matrix=None):
+        """shader: VS_COLORED_TRIANGLE / VS_COLORED_TRIANGLE_MESH -> (clip [n,4], varyings [n,8])"""
+        clip = np.empty((n_vertices, 4), dtype=np.float32)
+        var = np.empty((n_vertices, 8), dtype=np.float32)
+        mat = _f16m(render_matrix) if render_matrix is not None else None
+        self.lib.check(self.lib.lib.svr_run_vertex_shader(self.h, shader, mesh, first_vertex, n_vertices, mat,
+                                                          clip.ctypes.data, var.ctypes.data))
         return clip, var
 
     def set_option(self, option, value):

@@ -343,6 +343,25 @@ __global__ __launch_bounds__(256) void mesh_vert_kernel(const SvrVertex* vtx, ui
   reinterpret_cast<float4*>(out_var)[2 * i + 1] = make_float4(o.attr[4], o.attr[5], o.attr[6], o.attr[7]);
 }
 
+// colored_triangle.vert (vtx == nullptr: the vertex index is all it reads) and colored_triangle_mesh.vert as operators
+__global__ __launch_bounds__(256) void vertex_shader_kernel(const SvrVertex* vtx, uint32_t first, uint32_t n,
+                                                            const float* matrix16, float* out_clip, float* out_var) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  VOut o;
+  if (vtx) {
+    float m[16];
+    for (int k = 0; k < 16; k++) m[k] = matrix16[k];
+    VertexRaw v = load_vertex(vtx, first + i);
+    colored_triangle_mesh_vert(v, m, o);
+  } else {
+    colored_triangle_vert((int)(first + i), o);
+  }
+  reinterpret_cast<float4*>(out_clip)[i] = make_float4(o.clip[0], o.clip[1], o.clip[2], o.clip[3]);
+  reinterpret_cast<float4*>(out_var)[2 * i] = make_float4(o.attr[0], o.attr[1], o.attr[2], o.attr[3]);
+  reinterpret_cast<float4*>(out_var)[2 * i + 1] = make_float4(o.attr[4], o.attr[5], o.attr[6], o.attr[7]);
+}
+
 void launch_setup(const FrameParams& P, hipStream_t s) {
   if (P.n_chunks == 0) return;
   uint32_t blocks = (P.n_chunks + 3) / 4;
@@ -392,6 +411,12 @@ void launch_mesh_vert(const SvrVertex* vtx, uint32_t first, uint32_t n, const fl
   if (n == 0) return;
   hipLaunchKernelGGL(mesh_vert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, vtx, first, n, world16, viewproj16,
                      color_factors4, out_clip, out_varyings);
+}
+
+void launch_vertex_shader(const SvrVertex* vtx, uint32_t first, uint32_t n, const float* matrix16, float* out_clip,
+                          float* out_varyings, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(vertex_shader_kernel, dim3((n + 255) / 256), dim3(256), 0, s, vtx, first, n, matrix16, out_clip, out_varyings);
 }
 
 }  // namespace svr

@@ -1492,6 +1492,41 @@ int svr_run_mesh_vert(SvrContext* ctx, SvrMesh mesh, uint32_t first_vertex, uint
   return rc;
 }
 
+int svr_run_vertex_shader(SvrContext* ctx, int shader, SvrMesh mesh, uint32_t first_vertex, uint32_t n_vertices,
+                          const float render_matrix[16], float* out_clip, float* out_varyings) {
+  if (!ctx || !out_clip || !out_varyings) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_run_vertex_shader: null argument");
+  MeshRes* m = nullptr;
+  if (shader == SVR_VS_COLORED_TRIANGLE) {
+    if ((uint64_t)first_vertex + n_vertices > 3) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_run_vertex_shader: colored_triangle.vert has 3 vertices");
+  } else if (shader == SVR_VS_COLORED_TRIANGLE_MESH) {
+    if (!render_matrix) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_run_vertex_shader: null matrix");
+    m = get_mesh(ctx, mesh);
+    if (!m) return fail(SVR_ERR_BAD_HANDLE, "svr_run_vertex_shader: bad mesh");
+    if ((uint64_t)first_vertex + n_vertices > m->n_vtx)
+      return fail(SVR_ERR_INVALID_ARGUMENT, "svr_run_vertex_shader: vertex range outside the mesh");
+  } else {
+    return fail(SVR_ERR_INVALID_ARGUMENT, "svr_run_vertex_shader: unknown shader");
+  }
+  if (n_vertices == 0) return SVR_OK;
+  if (int e = use_device(ctx)) return e;
+  float* d_buf = nullptr;  // 16 floats of matrix, then clip, then varyings
+  if (hipMalloc((void**)&d_buf, (16 + (size_t)n_vertices * 12) * sizeof(float)) != hipSuccess)
+    return fail(SVR_ERR_OUT_OF_MEMORY, "svr_run_vertex_shader: hipMalloc failed");
+  int rc = SVR_OK;
+  do {
+    float zero[16] = {0};
+    if (hipMemcpy(d_buf, render_matrix ? render_matrix : zero, 64, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(SVR_ERR_DEVICE, "hipMemcpy"); break; }
+    float* d_clip = d_buf + 16;
+    float* d_var = d_clip + (size_t)n_vertices * 4;
+    launch_vertex_shader(m ? m->vtx : nullptr, first_vertex, n_vertices, d_buf, d_clip, d_var, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = fail(SVR_ERR_DEVICE, "vertex shader kernel failed"); break; }
+    if (hipMemcpy(out_clip, d_clip, (size_t)n_vertices * 16, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(SVR_ERR_DEVICE, "hipMemcpy"); break; }
+    if (hipMemcpy(out_varyings, d_var, (size_t)n_vertices * 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(SVR_ERR_DEVICE, "hipMemcpy"); break; }
+  } while (0);
+  (void)hipFree(d_buf);
+  return rc;
+}
+
 int svr_set_option(SvrContext* ctx, int option, int64_t value) {
   if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
   if (option == SVR_OPT_COUNT_FRAGMENTS) {

@@ -14,6 +14,9 @@ void launch_clip(const FrameParams& P, hipStream_t s);
 void launch_mesh_vert(const SvrVertex* vtx, uint32_t first, uint32_t n, const float* world16,
                       const float* viewproj16, const float* color_factors4, float* out_clip,
                       float* out_varyings, hipStream_t s);
+// vtx == nullptr: colored_triangle.vert (index only); else colored_triangle_mesh.vert with matrix16 (device memory)
+void launch_vertex_shader(const SvrVertex* vtx, uint32_t first, uint32_t n, const float* matrix16, float* out_clip,
+                          float* out_varyings, hipStream_t s);
 // k_flatten.hip
 void launch_flatten(const FlattenParams& F, hipStream_t s);
 // k_bin.hip
