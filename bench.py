@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--min-gain", type=float, default=0.2, help="N > 1: a cost-balanced cut replaces the equal bands only if it shortens the heaviest band by this fraction (unequal bands cost the host a batch of send/recv per frame instead of one all-gather)")
     ap.add_argument("--rebalance", type=int, default=64, help="N > 1: frames between two re-cuts of the row bands (0 = never)")
     ap.add_argument("--gather-fp16", action="store_true", help="N > 1: all-gather the RGBA16F target instead of the swapchain image")
-    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=10)
     ap.add_argument("--blocks", type=int, default=25, help="repetitions of the timed --steps block (the median block is reported)")
     ap.add_argument("--profile-tag", default="r02_i", help="profiles/<tag>_traffic.json and <tag>_valu.json of this build are quoted in the line")
     return ap.parse_args()
@@ -76,7 +76,6 @@ def host_cores():
             n = min(n, max(1, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
-    n = min(n, 64)  # the oracle's band-parallel rasteriser stops scaling long before (its geometry half is one thread)
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -90,10 +89,10 @@ def host_cores():
 
 
 def cpu_baseline(args, pkg, shaded_per_frame, sc):
-    """The oracle — a scalar C++ restatement of the path, NOT a binned rasteriser: geometry runs on one thread,
-    rasterisation is split into 16-row bands and every band walks every triangle (oracle/svr_oracle.cpp
-    raster_rows) — on this host's cores, same workload, bounded: one frame on one thread, then --cpu-frames
-    frames on every core this process may use."""
+    """The oracle — a scalar C++ restatement of the path, NOT a binned rasteriser: the draws are set up side by side
+    over the threads, rasterisation is split into 16-row bands over the threads, each walking the triangles that reach
+    it (oracle/svr_oracle.cpp run_pass / raster_rows) — on this host's cores, same workload, bounded: --cpu-frames
+    frames on every core this process may use, then one frame on one thread."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import svr_testlib as T
     ora = T.load_oracle()
