@@ -216,6 +216,24 @@ int svr_read_swapchain(SvrContext* ctx, uint32_t dst_width, uint32_t dst_height,
  * (0,0,width,height).  Pixels outside the scissor are left untouched (colour AND depth). */
 int svr_set_scissor(SvrContext* ctx, uint32_t x, uint32_t y, uint32_t w, uint32_t h);
 
+/* The interleaved multi-GPU partition ("row_tile % G == r"): of the 32-row tile rows of the
+ * scissor, counted from its first row (tile row t = rows y + 32 t .. y + 32 t + 31), this context renders those with
+ * t % stride == offset; stride 1 (the default) = all of them.  Everything that is said to write "the rows of the
+ * scissor" then writes the context's own tile rows — passes (colour and depth), svr_copy_to_swapchain at the identity
+ * extent (in place: row y of the target is row y of the image) — or at least those (svr_clear_color,
+ * svr_draw_background).  Triangles that meet none of the rows are dropped behind the vertex stage.  svr_get_row_costs
+ * numbers the context's own tile rows 0, 1, ...: its row i is tile row i * stride + offset.  A context that owns no tile
+ * row draws nothing (svr_draw_geometry returns SVR_OK).  1 <= stride <= 64. */
+int svr_set_row_interleave(SvrContext* ctx, uint32_t stride, uint32_t offset);
+
+/* Where a present reports whether it was carried out: every svr_copy_to_swapchain from now on also stores, on the
+ * stream, 0 to *status_dev when it wrote its rows and 1 when it was void — a pass in front of it overflowed an
+ * internal queue and everything since awaits the replay (SVR_OPT_QUEUE_CAPS).  The replay runs the present again
+ * and stores 0.  For callers that hand the image on by their own stream work (the exchange of include/svr_dist.h),
+ * which the replay cannot see: they read the word behind their own work and, when it is 1, fence (svr_sync) and
+ * hand the image on again.  NULL (the default): no report.  The oracle takes a host pointer and always stores 0. */
+int svr_set_present_status(SvrContext* ctx, uint32_t* status_dev);
+
 /* VulkanEngine::draw_geometry (src/vk_engine.cpp:1357-1477): cull opaque with is_visible, sort,
  * begin rendering (colour LOAD, depth CLEAR 0.0), draw opaque then transparent with
  * mesh.vert/mesh.frag, end.  The arrays are borrowed for the duration of the call. */
@@ -306,8 +324,9 @@ int svr_debug_read_tile_cycles(SvrContext* ctx, uint32_t* cycles, size_t capacit
  * 40 + opaque bin entries / 8 + 3/4 transparent bin entries (thousands of cycles, the model the tile kernel's own
  * split rule is fitted to).  Does not wait for passes in flight: it reports the last one whose completion the
  * context has already seen (none yet: *n_tile_rows = 0).  *first_row / *n_rows: that pass's scissor rows; tile row t
- * covers rows first_row + 32 t .. + 31 (clipped to the scissor).  costs may be NULL to query the count.  HIP library:
- * measured; oracle: 1 per tile row (it has no bins). */
+ * covers rows first_row + 32 t .. + 31 (clipped to the scissor) — of the context's OWN tile rows when they are
+ * interleaved (svr_set_row_interleave: its row t is tile row t * stride + offset).  costs may be NULL to query the
+ * count.  HIP library: measured; oracle: 1 per tile row (it has no bins). */
 int svr_get_row_costs(SvrContext* ctx, uint32_t* costs, size_t capacity, uint32_t* n_tile_rows, uint32_t* first_row,
                       uint32_t* n_rows);
 

@@ -177,6 +177,9 @@ struct SvrContext {
   std::vector<uint8_t> color8;    // RGBA8
   std::vector<float> depth;
   uint32_t sx = 0, sy = 0, sw = 0, sh = 0;
+  uint32_t rstride = 1, roff = 0;      // svr_set_row_interleave
+  uint32_t pass_rstride = 1;
+  uint32_t* present_status = nullptr;  // svr_set_present_status (a host pointer here)
   uint32_t pass_sy = 0, pass_sh = 0;  // scissor rows of the last pass (svr_get_row_costs)
   std::vector<std::unique_ptr<Mesh>> meshes;
   std::vector<std::unique_ptr<Image>> images;
@@ -650,6 +653,11 @@ inline void store_color(SvrContext* ctx, size_t p, const float c[4]) {
     for (int k = 0; k < 4; k++) ctx->color8[p * 4 + k] = f32_to_unorm8(c[k]);
 }
 
+// svr_set_row_interleave: of the scissor's 32-row tile rows the context renders those with index % rstride == roff
+inline bool owns_row(const SvrContext* ctx, uint32_t y) {
+  return ctx->rstride == 1u || ((y - ctx->sy) >> 5) % ctx->rstride == ctx->roff;
+}
+
 // rasterise rows [y0,y1) of every triangle, in submission order
 // subset (may be null): the triangles, in submission order, that reach rows y0 .. y1 - 1 — the threaded path hands
 // every band its own list; submission order within a pixel is the order of `tris` either way.
@@ -661,6 +669,7 @@ void raster_rows(SvrContext* ctx, const SvrSceneData* scene, const std::vector<S
     const SetupTri& t = subset ? *(*subset)[ti] : tris[ti];
     int ya = std::max(t.miny, y0), yb = std::min(t.maxy, y1 - 1);
     for (int py = ya; py <= yb; py++) {
+      if (!owns_row(ctx, (uint32_t)py)) continue;  // svr_set_row_interleave
       for (int px = t.minx; px <= t.maxx; px++) {
         int64_t e0 = t.A[0] * px + t.B[0] * py + t.C[0];
         int64_t e1 = t.A[1] * px + t.B[1] * py + t.C[1];
@@ -721,6 +730,7 @@ inline void row_run(int y0, int y1, int n, int ti, int& a, int& b) {
 int run_pass(SvrContext* ctx, const SvrSceneData* scene, const std::vector<DrawCmd>& cmds) {
   ctx->pass_sy = ctx->sy;
   ctx->pass_sh = ctx->sh;
+  ctx->pass_rstride = ctx->rstride;
   PassState ps;
   ps.ctx = ctx;
   const int nthreads = std::max(1, ctx->threads);
@@ -1135,9 +1145,11 @@ int svr_draw_background(SvrContext* ctx, int effect, const float data[16]) {
 }
 
 // ---- vkutil::copy_image (src/vk_images.cpp:33-64): LINEAR blit to the swapchain format  (contract C16)
-static int blit_to(SvrContext* ctx, uint32_t dw, uint32_t dh, int fmt, uint8_t* dst, uint32_t row_first, uint32_t n_rows) {
+static int blit_to(SvrContext* ctx, uint32_t dw, uint32_t dh, int fmt, uint8_t* dst, uint32_t row_first, uint32_t n_rows,
+                   bool own_rows_only = false) {
   const float su = (float)ctx->W / (float)dw, sv = (float)ctx->H / (float)dh;
-  for (uint32_t j = row_first; j < row_first + n_rows; j++)
+  for (uint32_t j = row_first; j < row_first + n_rows; j++) {
+    if (own_rows_only && !owns_row(ctx, j)) continue;
     for (uint32_t i = 0; i < dw; i++) {
       float u = ((float)i + 0.5f) * su - 0.5f, v = ((float)j + 0.5f) * sv - 0.5f;
       float fu = std::floor(u), fv = std::floor(v);
@@ -1162,6 +1174,7 @@ static int blit_to(SvrContext* ctx, uint32_t dw, uint32_t dh, int fmt, uint8_t* 
         for (int c = 0; c < 4; c++) d[c] = f32_to_unorm8(o[c]);
       }
     }
+  }
   return SVR_OK;
 }
 
@@ -1181,7 +1194,22 @@ int svr_copy_to_swapchain(SvrContext* ctx, void* dst, uint32_t dw, uint32_t dh, 
   if (fmt != SVR_SWAPCHAIN_B8G8R8A8 && fmt != SVR_SWAPCHAIN_R8G8B8A8)
     return fail(SVR_ERR_INVALID_ARGUMENT, "svr_copy_to_swapchain: unknown format");
   const bool identity = dw == ctx->W && dh == ctx->H;  // identity extent: the scissor's rows only
-  return blit_to(ctx, dw, dh, fmt, (uint8_t*)dst, identity ? ctx->sy : 0u, identity ? ctx->sh : dh);
+  if (ctx->present_status) *ctx->present_status = 0u;  // nothing here is ever void
+  return blit_to(ctx, dw, dh, fmt, (uint8_t*)dst, identity ? ctx->sy : 0u, identity ? ctx->sh : dh, identity);
+}
+
+int svr_set_row_interleave(SvrContext* ctx, uint32_t stride, uint32_t offset) {
+  if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  if (stride == 0 || stride > 64 || offset >= stride) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_set_row_interleave: need 1 <= stride <= 64, offset < stride");
+  ctx->rstride = stride;
+  ctx->roff = offset;
+  return SVR_OK;
+}
+
+int svr_set_present_status(SvrContext* ctx, uint32_t* status) {
+  if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  ctx->present_status = status;
+  return SVR_OK;
 }
 
 int svr_set_scissor(SvrContext* ctx, uint32_t x, uint32_t y, uint32_t w, uint32_t h) {
@@ -1393,7 +1421,8 @@ int svr_debug_read_bins(SvrContext*, uint32_t*, size_t, uint32_t*) {
 
 int svr_get_row_costs(SvrContext* ctx, uint32_t* costs, size_t capacity, uint32_t* n_tile_rows, uint32_t* first_row, uint32_t* n_rows) {
   if (!ctx || !n_tile_rows) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_get_row_costs: null argument");
-  const uint32_t n = (ctx->pass_sh + 31u) / 32u;  // the oracle has no bins to weigh: every tile row costs the same
+  uint32_t n = (ctx->pass_sh + 31u) / 32u;  // the oracle has no bins to weigh: every tile row costs the same
+  n = n > ctx->roff ? (n - ctx->roff + ctx->pass_rstride - 1u) / ctx->pass_rstride : 0u;  // the context's own tile rows
   *n_tile_rows = n;
   if (first_row) *first_row = ctx->pass_sy;
   if (n_rows) *n_rows = ctx->pass_sh;

@@ -82,7 +82,7 @@ SYMBOLS = ["svr_create", "svr_destroy", "svr_set_stream", "svr_bind_targets", "s
            "svr_upload_mesh", "svr_destroy_mesh", "svr_create_image", "svr_destroy_image",
            "svr_read_image_level", "svr_create_sampler", "svr_write_material", "svr_clear_color",
            "svr_draw_background", "svr_copy_to_swapchain", "svr_read_swapchain",
-           "svr_set_scissor", "svr_draw_geometry", "svr_draw_colored_triangle", "svr_draw_tex_image",
+           "svr_set_scissor", "svr_set_row_interleave", "svr_set_present_status", "svr_draw_geometry", "svr_draw_colored_triangle", "svr_draw_tex_image",
            "svr_run_mesh_vert", "svr_run_vertex_shader", "svr_set_option", "svr_debug_trace_pixel", "svr_debug_read_trace", "svr_debug_read_bins", "svr_debug_read_tile_cycles", "svr_debug_rcp_sweep", "svr_get_row_costs", "svr_sync", "svr_read_color", "svr_read_depth", "svr_get_stats",
            "svr_last_error", "svr_backend_name"]
 
@@ -125,6 +125,9 @@ class SvrLib:
         L.svr_copy_to_swapchain.argtypes = [P, P, C.c_uint32, C.c_uint32, C.c_int]
         L.svr_read_swapchain.argtypes = [P, C.c_uint32, C.c_uint32, C.c_int, P, C.c_size_t]
         L.svr_set_scissor.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        if hasattr(L, "svr_set_row_interleave"):  # tools/ab_libs.py also loads builds that predate these
+            L.svr_set_row_interleave.argtypes = [P, C.c_uint32, C.c_uint32]
+            L.svr_set_present_status.argtypes = [P, P]
         L.svr_draw_geometry.argtypes = [P, C.POINTER(SvrSceneData), P, C.c_size_t, P, C.c_size_t,
                                         C.POINTER(SvrStats)]
         L.svr_draw_colored_triangle.argtypes = [P, C.POINTER(SvrStats)]
@@ -283,6 +286,14 @@ class Renderer:
 
     def set_scissor(self, x, y, w, h):
         self.lib.check(self.lib.lib.svr_set_scissor(self.h, x, y, w, h))
+
+    def set_row_interleave(self, stride, offset):
+        """of the scissor's 32-row tile rows render those with index % stride == offset (1, 0: all)"""
+        self.lib.check(self.lib.lib.svr_set_row_interleave(self.h, stride, offset))
+
+    def set_present_status(self, status_ptr):
+        """device word (oracle: host word) every copy_to_swapchain reports to: 1 = void, awaiting the replay"""
+        self.lib.check(self.lib.lib.svr_set_present_status(self.h, C.c_void_p(status_ptr)))
 
     def _objects(self, a):
         """(address, count) of a RenderObject list; arrays of the right kind are passed as they are, and their address is

@@ -72,7 +72,7 @@ __device__ __forceinline__ void bin_rest(const FrameParams& P, uint32_t first_wa
         int ty = tr.ty0 + t / tr.ntx, tx = tr.tx0 + t % tr.ntx;
         if (tr.nt > 4) {
           int x0 = max(b.minx, (int)P.sx + tx * TILE), x1 = min(b.maxx, (int)P.sx + tx * TILE + TILE - 1);
-          int y0 = max(b.miny, (int)P.sy + ty * TILE), y1 = min(b.maxy, (int)P.sy + ty * TILE + TILE - 1);
+          int y0 = max(b.miny, tile_row_y(P, ty)), y1 = min(b.maxy, tile_row_y(P, ty) + TILE - 1);
           hit = box_overlaps(e, x0, y0, x1, y1);
         }
         bin = binbase + (uint32_t)ty * P.tiles_x + (uint32_t)tx;

@@ -198,14 +198,26 @@ __device__ __forceinline__ float4 load_target(const void* color, int fmt, size_t
   const float k = 0x1.010102p-8f;
   return make_float4((float)(t & 0xffu) * k, (float)((t >> 8) & 0xffu) * k, (float)((t >> 16) & 0xffu) * k, (float)(t >> 24) * k);
 }
+// rstride > 1 (identity extent only): of the 32-row tile rows counted from row_first, those with index % rstride == roff
+// (svr_set_row_interleave) — n_rows is then 32 x the number of such tile rows and row_end the first row not to write.
+// status (may be null): receives 1 when the blit is void (an earlier pass overflowed: the replay will run it again), else 0
 __global__ __launch_bounds__(256) void blit_kernel(const void* color, int fmt, uint32_t W, uint32_t H, uint32_t* dst, uint32_t dw,
                                                    uint32_t dh, uint32_t row_first, uint32_t n_rows, int dst_format,
-                                                   const uint32_t* poison) {
-  if (*poison) return;
+                                                   const uint32_t* poison, uint32_t rstride, uint32_t roff, uint32_t row_end,
+                                                   uint32_t* status) {
+  const uint32_t void_op = *poison;
+  if (status && blockIdx.x == 0 && threadIdx.x == 0) *status = void_op ? 1u : 0u;
+  if (void_op) return;
   const float su = (float)W / (float)dw, sv = (float)H / (float)dh;
   const uint32_t n = dw * n_rows;  // destination rows [row_first, row_first + n_rows)
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-    uint32_t i = k % dw, j = row_first + k / dw, idx = j * dw + i;
+    uint32_t i = k % dw, j = row_first + k / dw;
+    if (rstride > 1u) {
+      const uint32_t lr = k / dw;  // row among the owned ones
+      j = row_first + ((lr >> 5) * rstride + roff) * 32u + (lr & 31u);
+      if (j >= row_end) continue;
+    }
+    const uint32_t idx = j * dw + i;
     float u = ((float)i + 0.5f) * su - 0.5f, v = ((float)j + 0.5f) * sv - 0.5f;
     float fu = floorf(u), fv = floorf(v);
     float a = u - fu, b = v - fv;
@@ -225,9 +237,10 @@ __global__ __launch_bounds__(256) void blit_kernel(const void* color, int fmt, u
   }
 }
 void launch_blit(const void* color, int color_format, uint32_t W, uint32_t H, void* dst, uint32_t dw, uint32_t dh, uint32_t row_first,
-                 uint32_t n_rows, int dst_format, const uint32_t* poison, hipStream_t s) {
-  hipLaunchKernelGGL(blit_kernel, dim3(stream_grid(dw * n_rows)), dim3(256), 0, s, color, color_format, W, H, (uint32_t*)dst, dw, dh,
-                     row_first, n_rows, dst_format, poison);
+                 uint32_t n_rows, int dst_format, const uint32_t* poison, uint32_t rstride, uint32_t roff, uint32_t row_end, uint32_t* status,
+                 hipStream_t s) {
+  hipLaunchKernelGGL(blit_kernel, dim3(stream_grid(std::max(dw * n_rows, 1u))), dim3(256), 0, s, color, color_format, W, H, (uint32_t*)dst, dw,
+                     dh, row_first, n_rows, dst_format, poison, rstride, roff, row_end, status);
 }
 
 // Test hook: the contract's "IEEE 1/x" as the kernels compute it (rcp_ieee / its candidate refinements)

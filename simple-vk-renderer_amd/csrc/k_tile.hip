@@ -1004,7 +1004,7 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
   constexpr int nrows = 4 << lrpw;
   const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  const int tx0 = (int)(P.sx + tx * TILE), ty0 = (int)(P.sy + ty * TILE);
+  const int tx0 = (int)(P.sx + tx * TILE), ty0 = tile_row_y(P, (int)ty);
   const int x_end = (int)(P.sx + P.sw), y_end = (int)(P.sy + P.sh);
   const int sub_y0 = ty0 + row0;
   // pixel ownership: wave w the 16x16 quadrant w, lane l one pixel in each of its four 8x8 blocks; slot k of a
@@ -1297,8 +1297,9 @@ __global__ __launch_bounds__(256, SVR_TILE_WAVES) void tile_kernel(FrameParams P
   const uint4 i0 = make_uint4(w0, w1, w2, w3), i1 = make_uint4(w4, w5, w6, w7);
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // this wave's number, for tid_of()
 
-  if (blockIdx.x == 0 && threadIdx.x < P.tiles_y)  // the pass's cost per tile row, for the host (nobody waits for it)
-    __hip_atomic_store(P.host_row_cost + threadIdx.x, P.row_cost[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (blockIdx.x == 0)  // the pass's cost per tile row, for the host (nobody waits for it)
+    for (uint32_t r = threadIdx.x; r < min(P.tiles_y, ROW_COST_MAX); r += blockDim.x)
+      __hip_atomic_store(P.host_row_cost + r, P.row_cost[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // A pass that overflowed a queue is void, and so is everything after it until the host has replayed
   // it (svr_api.hip "the operation log"): the targets stay as they were before the failed pass.
   if (overflow | poison) {

@@ -113,6 +113,8 @@ struct SvrContext {
   void* color = nullptr;
   float* depth = nullptr;
   uint32_t sx = 0, sy = 0, sw = 0, sh = 0;
+  uint32_t rstride = 1, roff = 0;      // svr_set_row_interleave
+  uint32_t* present_status = nullptr;  // svr_set_present_status
 
   std::vector<MeshRes> meshes;
   std::vector<ImageRes> images;
@@ -164,6 +166,8 @@ struct SvrContext {
     void* blit_dst = nullptr;
     uint32_t blit_w = 0, blit_h = 0;
     int blit_fmt = 0;
+    uint32_t blit_rstride = 1, blit_roff = 0, blit_row_end = 0;  // identity blits of an interleaved pass: its tile rows only
+    uint32_t* blit_status = nullptr;
     FrameParams P{};  // pass: parameters as recorded + its draw list
     std::vector<DrawDesc> draws;
     // device-flattened pass: the caller's objects (opaque, then transparent) instead of a draw list
@@ -581,7 +585,7 @@ int submit_clear(SvrContext* ctx, const SvrContext::LoggedOp& op) {  // every lo
     launch_background(op.target, op.clear_fmt, op.tw, op.th, op.y_first, op.n_rows, op.bg_effect, op.bg_data, ctx->d_poison, ctx->stream);
   else
     launch_blit(op.target, op.clear_fmt, op.tw, op.th, op.blit_dst, op.blit_w, op.blit_h, op.y_first, op.n_rows, op.blit_fmt, ctx->d_poison,
-                ctx->stream);
+                op.blit_rstride, op.blit_roff, op.blit_row_end, op.blit_status, ctx->stream);
   HIPCHK(hipGetLastError());
   return SVR_OK;
 }
@@ -734,6 +738,12 @@ int finish_pending(SvrContext* ctx) {  // the fence
 }
 int poll_pending(SvrContext* ctx) { return retire_ops(ctx, false); }
 
+// the scissor's 32-row tile rows this context renders (svr_set_row_interleave: index % rstride == roff)
+uint32_t owned_tile_rows(const SvrContext* ctx) {
+  const uint32_t all = (ctx->sh + TILE - 1) / TILE;
+  return all > ctx->roff ? (all - ctx->roff + ctx->rstride - 1) / ctx->rstride : 0u;
+}
+
 int fill_frame_params(SvrContext* ctx, const SvrSceneData* scene, uint64_t n_tris64, size_t n_chunks, FrameParams& P) {
   if (n_tris64 >= 0x3ffffff0ull) return fail(SVR_ERR_UNSUPPORTED, "more than 2^30 triangles in one pass");
   std::memset(&P, 0, sizeof(P));
@@ -746,7 +756,9 @@ int fill_frame_params(SvrContext* ctx, const SvrSceneData* scene, uint64_t n_tri
   P.sw = ctx->sw;
   P.sh = ctx->sh;
   P.tiles_x = (ctx->sw + TILE - 1) / TILE;
-  P.tiles_y = (ctx->sh + TILE - 1) / TILE;
+  P.rstride = ctx->rstride;
+  P.roff = ctx->roff;
+  P.tiles_y = owned_tile_rows(ctx);
   P.n_tiles = P.tiles_x * P.tiles_y;
   P.n_tris = (uint32_t)n_tris64;
   P.n_chunks = (uint32_t)n_chunks;
@@ -1281,6 +1293,13 @@ int svr_copy_to_swapchain(SvrContext* ctx, void* dst_dev, uint32_t dw, uint32_t 
   const bool identity = dw == ctx->W && dh == ctx->H;
   op.y_first = identity ? ctx->sy : 0u;
   op.n_rows = identity ? ctx->sh : dh;
+  op.blit_row_end = op.y_first + op.n_rows;
+  if (identity && ctx->rstride > 1u) {  // a rank of the interleaved form presents its own tile rows, in place
+    op.blit_rstride = ctx->rstride;
+    op.blit_roff = ctx->roff;
+    op.n_rows = owned_tile_rows(ctx) * TILE;
+  }
+  op.blit_status = ctx->present_status;
   return submit_clear(ctx, op);
 }
 
@@ -1290,7 +1309,7 @@ int svr_read_swapchain(SvrContext* ctx, uint32_t dw, uint32_t dh, int fmt, void*
   if (int e = use_device(ctx)) return e;
   if (int e = finish_pending(ctx)) return e;  // the read-back is a fence
   if (int e = ctx->d_cvt.ensure((size_t)dw * dh * 4)) return e;
-  launch_blit(ctx->color, ctx->fmt, ctx->W, ctx->H, ctx->d_cvt.p, dw, dh, 0, dh, fmt, ctx->d_poison, ctx->stream);
+  launch_blit(ctx->color, ctx->fmt, ctx->W, ctx->H, ctx->d_cvt.p, dw, dh, 0, dh, fmt, ctx->d_poison, 1u, 0u, dh, nullptr, ctx->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(dst_host, ctx->d_cvt.p, (size_t)dw * dh * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1305,6 +1324,20 @@ int svr_set_scissor(SvrContext* ctx, uint32_t x, uint32_t y, uint32_t w, uint32_
   ctx->sy = y;
   ctx->sw = w;
   ctx->sh = h;
+  return SVR_OK;
+}
+
+int svr_set_row_interleave(SvrContext* ctx, uint32_t stride, uint32_t offset) {
+  if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  if (stride == 0 || stride > 64 || offset >= stride) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_set_row_interleave: need 1 <= stride <= 64, offset < stride");
+  ctx->rstride = stride;
+  ctx->roff = offset;
+  return SVR_OK;
+}
+
+int svr_set_present_status(SvrContext* ctx, uint32_t* status_dev) {
+  if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  ctx->present_status = status_dev;
   return SVR_OK;
 }
 
@@ -1335,6 +1368,12 @@ int svr_draw_geometry(SvrContext* ctx, const SvrSceneData* scene, const SvrRende
     if (int e = validate_object(ctx, opaque[i], false)) return e;
   for (size_t i = 0; i < n_transparent; i++)
     if (int e = validate_object(ctx, transparent[i], true)) return e;
+  if (owned_tile_rows(ctx) == 0) {  // interleaved rows and more ranks than tile rows: this one owns nothing
+    ctx->pending_clear.valid = false;
+    ctx->stats = SvrStats{};
+    if (out_stats) *out_stats = ctx->stats;
+    return SVR_OK;
+  }
   if (ctx->tex_slots != ctx->materials.size() + 1)
     if (int e = upload_tex_table(ctx, nullptr)) return e;
   // Many objects: cull, sort and the per-object records run on the device (k_flatten.hip).  The three
@@ -1403,6 +1442,7 @@ int svr_draw_geometry(SvrContext* ctx, const SvrSceneData* scene, const SvrRende
 
 int svr_draw_colored_triangle(SvrContext* ctx, SvrStats* out_stats) {
   if (!ctx) return fail(SVR_ERR_INVALID_ARGUMENT, "null context");
+  if (owned_tile_rows(ctx) == 0) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_colored_triangle: this context owns no tile row (svr_set_row_interleave)");
   if (int e = use_device(ctx)) return e;
   if (ctx->tex_slots != ctx->materials.size() + 1)
     if (int e = upload_tex_table(ctx, nullptr)) return e;
@@ -1429,6 +1469,7 @@ int svr_draw_tex_image(SvrContext* ctx, SvrMesh mesh, uint32_t first_index, uint
   if (sampler == 0 || sampler > ctx->samplers.size()) return fail(SVR_ERR_BAD_HANDLE, "svr_draw_tex_image: bad sampler");
   if ((uint64_t)first_index + index_count > m->n_idx)
     return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_tex_image: index range outside the mesh");
+  if (owned_tile_rows(ctx) == 0) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_draw_tex_image: this context owns no tile row (svr_set_row_interleave)");
   if (int e = use_device(ctx)) return e;
   if (int e = finish_pending(ctx)) return e;  // the scratch binding slot is about to change
   TexBinding tb = make_binding(*im, ctx->samplers[sampler - 1]);

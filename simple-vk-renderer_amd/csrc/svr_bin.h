@@ -27,10 +27,11 @@ struct TileRange {
 __device__ __forceinline__ TileRange tile_range(const FrameParams& P, int minx, int miny, int maxx, int maxy, bool valid) {
   TileRange t;
   t.tx0 = (minx - (int)P.sx) >> TILE_SHIFT;
-  t.ty0 = (miny - (int)P.sy) >> TILE_SHIFT;
+  int l1;
+  local_tile_rows(P, miny, maxy, t.ty0, l1);  // the pass's own tile rows (all of them unless the rows are interleaved)
   t.ntx = ((maxx - (int)P.sx) >> TILE_SHIFT) - t.tx0 + 1;
-  int nty = ((maxy - (int)P.sy) >> TILE_SHIFT) - t.ty0 + 1;
-  t.nt = valid ? t.ntx * nty : 0;
+  int nty = l1 - t.ty0 + 1;
+  t.nt = (valid && nty > 0) ? t.ntx * nty : 0;
   return t;
 }
 
@@ -50,7 +51,7 @@ __device__ __forceinline__ void emit_small_pairs(const FrameParams& P, bool smal
       int tx = tr.tx0, ty = tr.ty0;  // running tile coordinates: no integer division per tile
       for (int j = 0; j < tr.nt; j++) {
         int x0 = max(minx, (int)P.sx + tx * TILE), x1 = min(maxx, (int)P.sx + tx * TILE + TILE - 1);
-        int y0 = max(miny, (int)P.sy + ty * TILE), y1 = min(maxy, (int)P.sy + ty * TILE + TILE - 1);
+        int y0 = max(miny, tile_row_y(P, ty)), y1 = min(maxy, tile_row_y(P, ty) + TILE - 1);
         if (box_overlaps(e, x0, y0, x1, y1)) mask |= 1u << j;
         if (++tx == tr.tx0 + tr.ntx) {
           tx = tr.tx0;

@@ -178,6 +178,8 @@ struct FrameParams {
   uint32_t W, H;                  // target extent == viewport
   uint32_t sx, sy, sw, sh;        // scissor
   uint32_t tiles_x, tiles_y, n_tiles;
+  uint32_t rstride, roff;         // svr_set_row_interleave: of the scissor's 32-row tile rows this pass owns those with
+                                  // index % rstride == roff; tiles_y, bins and row costs count the owned rows only
   // geometry
   const DrawDesc* draws;
   const WaveChunk* chunks;
@@ -237,6 +239,22 @@ struct FlattenParams {
 };
 
 // ------------------------------------------------------------------------------------------------
+// The tile rows a pass owns (svr_set_row_interleave): first pixel row of its local tile row `ty` ...
+__device__ __forceinline__ int tile_row_y(const FrameParams& P, int ty) {
+  return (int)P.sy + (ty * (int)P.rstride + (int)P.roff) * TILE;
+}
+// ... and the local tile rows [l0, l1] that pixel rows [miny, maxy] (inside the scissor) meet; none: l0 > l1
+__device__ __forceinline__ void local_tile_rows(const FrameParams& P, int miny, int maxy, int& l0, int& l1) {
+  const int g0 = (miny - (int)P.sy) >> TILE_SHIFT, g1 = (maxy - (int)P.sy) >> TILE_SHIFT;
+  l0 = g0;
+  l1 = g1;
+  if (P.rstride > 1u) {  // pass-uniform
+    const int s = (int)P.rstride, b = g1 - (int)P.roff;
+    l0 = (g0 - (int)P.roff + s - 1) / s;  // ceil; the dividend is never negative (roff < rstride)
+    l1 = b < 0 ? -1 : b / s;
+  }
+}
+
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 
@@ -453,6 +471,11 @@ __device__ inline bool setup_triangle(const FrameParams& P, const VOut* v0, cons
   pmaxx = min(pmaxx, (int)(P.sx + P.sw) - 1);
   pmaxy = min(pmaxy, (int)(P.sy + P.sh) - 1);
   if (pminx > pmaxx || pminy > pmaxy) return false;
+  if (P.rstride > 1u) {  // a rank of the interleaved multi-GPU form: triangles that meet none of its tile rows go no further
+    int l0, l1;
+    local_tile_rows(P, pminy, pmaxy, l0, l1);
+    if (l0 > l1) return false;
+  }
 
   int Xs[3] = {X0, X1, X2}, Ys[3] = {Y0, Y1, Y2};
   double A[3], B[3], C[3];
