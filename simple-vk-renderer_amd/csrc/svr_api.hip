@@ -942,6 +942,7 @@ int svr_create(const SvrConfig* cfg, SvrContext** out) {
     if ((r = hipEventCreate(&ctx->op_done[i])) != hipSuccess || (r = hipEventCreate(&ctx->op_start[i])) != hipSuccess) return bail(r, "hipEventCreate");
   if ((r = hipHostMalloc((void**)&ctx->h_row_cost, sizeof(uint32_t) * ROW_COST_MAX * SvrContext::MAX_OPS, hipHostMallocDefault)) != hipSuccess)
     return bail(r, "hipHostMalloc");
+  std::memset(ctx->h_row_cost, 0, sizeof(uint32_t) * ROW_COST_MAX * SvrContext::MAX_OPS);
   if ((r = hipHostMalloc((void**)&ctx->h_failed_seq, 64, hipHostMallocDefault)) != hipSuccess) return bail(r, "hipHostMalloc");
   *ctx->h_failed_seq = 0;
   if ((r = hipMalloc((void**)&ctx->d_poison, 256)) != hipSuccess) return bail(r, "hipMalloc");
