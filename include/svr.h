@@ -229,9 +229,11 @@ int svr_set_row_interleave(SvrContext* ctx, uint32_t stride, uint32_t offset);
 /* Where a present reports whether it was carried out: every svr_copy_to_swapchain from now on also stores, on the
  * stream, 0 to *status_dev when it wrote its rows and 1 when it was void — a pass in front of it overflowed an
  * internal queue and everything since awaits the replay (SVR_OPT_QUEUE_CAPS).  The replay runs the present again
- * and stores 0.  For callers that hand the image on by their own stream work (the exchange of include/svr_dist.h),
- * which the replay cannot see: they read the word behind their own work and, when it is 1, fence (svr_sync) and
- * hand the image on again.  NULL (the default): no report.  The oracle takes a host pointer and always stores 0. */
+ * and stores 2.  For callers that hand the image on by their own stream work (the exchange of include/svr_dist.h),
+ * which the replay cannot see: they read the word behind their own work; 0 = the rows they handed on were final;
+ * anything else = they were stale (1) or may have been rewritten under the reader (2): fence (svr_sync), clear the
+ * word and hand the image on again.  NULL (the default): no report.  The oracle takes a host pointer and always
+ * stores 0. */
 int svr_set_present_status(SvrContext* ctx, uint32_t* status_dev);
 
 /* VulkanEngine::draw_geometry (src/vk_engine.cpp:1357-1477): cull opaque with is_visible, sort,

@@ -66,12 +66,33 @@ int svr_dist_rebalance(SvrDist* d, float measured_gpu_ms, int* changed);
  * empty (*rows = 0) skips its draw calls for the frame, but still begins and ends it */
 int svr_dist_band(SvrDist* d, uint32_t* first_row, uint32_t* rows);
 
+/* How the frame's rows are dealt out (SURVEY.md section 8e names both and says: measure).
+ *   SVR_DIST_BANDS        rank r renders the contiguous rows [bounds[r], bounds[r+1]) (above): every rank repeats only the
+ *                         geometry that can reach its band, but a band of few tile rows lasts as long as its deepest tile.
+ *   SVR_DIST_INTERLEAVED  rank r renders the 32-row tile rows t with t % world == r (svr_set_row_interleave): deep and
+ *                         shallow regions are dealt out evenly, every rank runs the whole scene's vertex stage.  The rows
+ *                         travel as one RCCL group of in-place all-gathers, one per `world` consecutive tile rows.
+ * set: every rank, between the same two frames; takes effect at the next svr_dist_begin_frame.
+ * pick: collective; every rank hands in what a frame cost it under either partition (GPU ms, measured over a few
+ * frames each); the partition whose SLOWEST rank is faster is chosen on every rank alike. */
+enum SvrDistPartition { SVR_DIST_BANDS = 0, SVR_DIST_INTERLEAVED = 1 };
+int svr_dist_set_partition(SvrDist* d, int partition);
+int svr_dist_get_partition(SvrDist* d, int* partition);
+int svr_dist_pick_partition(SvrDist* d, float bands_ms, float interleaved_ms, int* picked);
+
 int svr_dist_begin_frame(SvrDist* d);
 int svr_dist_end_frame(SvrDist* d);
 /* The oldest frame whose exchange has been started and not yet waited for: blocks until every band has
  * arrived; *image_dev = device pointer of the whole width x height x 4-byte image (valid until the slot's next
  * svr_dist_begin_frame).  SVR_ERR_INVALID_ARGUMENT when no frame is in flight. */
 int svr_dist_wait_frame(SvrDist* d, const void** image_dev);
+/* A pass that overflows the renderer's internal queues is void and replayed later (include/svr.h, SVR_OPT_QUEUE_CAPS),
+ * the present behind it too — but the exchange is this library's own stream work, which the replay knows nothing of: the
+ * rows that travelled were stale.  Every present therefore reports into a status word (svr_set_present_status) that
+ * travels with the rows; svr_dist_wait_frame finds a rank's word raised — on every rank alike, no extra message —
+ * fences the renderer (the replay runs there) and exchanges the slot again before it hands the image out: a frame it
+ * returns is a finished one (src/vk_engine.cpp:1226, 1332).  *n = frames that were exchanged a second time. */
+int svr_dist_replays(SvrDist* d, uint32_t* n);
 /* svr_dist_wait_frame + copy to host memory */
 int svr_dist_read_frame(SvrDist* d, void* dst_host, size_t bytes);
 

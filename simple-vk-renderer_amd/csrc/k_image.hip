@@ -200,13 +200,14 @@ __device__ __forceinline__ float4 load_target(const void* color, int fmt, size_t
 }
 // rstride > 1 (identity extent only): of the 32-row tile rows counted from row_first, those with index % rstride == roff
 // (svr_set_row_interleave) — n_rows is then 32 x the number of such tile rows and row_end the first row not to write.
-// status (may be null): receives 1 when the blit is void (an earlier pass overflowed: the replay will run it again), else 0
+// status (may be null): receives 1 when the blit is void (an earlier pass overflowed: the replay will run it again), else
+// status_ok — 0 from the blit as first enqueued, 2 from the replay's (whoever read the rows in between cannot trust them)
 __global__ __launch_bounds__(256) void blit_kernel(const void* color, int fmt, uint32_t W, uint32_t H, uint32_t* dst, uint32_t dw,
                                                    uint32_t dh, uint32_t row_first, uint32_t n_rows, int dst_format,
                                                    const uint32_t* poison, uint32_t rstride, uint32_t roff, uint32_t row_end,
-                                                   uint32_t* status) {
+                                                   uint32_t* status, uint32_t status_ok) {
   const uint32_t void_op = *poison;
-  if (status && blockIdx.x == 0 && threadIdx.x == 0) *status = void_op ? 1u : 0u;
+  if (status && blockIdx.x == 0 && threadIdx.x == 0) *status = void_op ? 1u : status_ok;
   if (void_op) return;
   const float su = (float)W / (float)dw, sv = (float)H / (float)dh;
   const uint32_t n = dw * n_rows;  // destination rows [row_first, row_first + n_rows)
@@ -238,9 +239,9 @@ __global__ __launch_bounds__(256) void blit_kernel(const void* color, int fmt, u
 }
 void launch_blit(const void* color, int color_format, uint32_t W, uint32_t H, void* dst, uint32_t dw, uint32_t dh, uint32_t row_first,
                  uint32_t n_rows, int dst_format, const uint32_t* poison, uint32_t rstride, uint32_t roff, uint32_t row_end, uint32_t* status,
-                 hipStream_t s) {
+                 uint32_t status_ok, hipStream_t s) {
   hipLaunchKernelGGL(blit_kernel, dim3(stream_grid(std::max(dw * n_rows, 1u))), dim3(256), 0, s, color, color_format, W, H, (uint32_t*)dst, dw,
-                     dh, row_first, n_rows, dst_format, poison, rstride, roff, row_end, status);
+                     dh, row_first, n_rows, dst_format, poison, rstride, roff, row_end, status, status_ok);
 }
 
 // Test hook: the contract's "IEEE 1/x" as the kernels compute it (rcp_ieee / its candidate refinements)

@@ -558,6 +558,14 @@ void note_pass_stats(SvrContext* ctx, const FrameParams&, const Counters& c) {  
   ctx->stats.binned_triangles = c.binned;
 }
 
+// the tile rows' costs of a finished pass (posted by its tile kernel before anything else): svr_get_row_costs
+void note_row_costs(SvrContext* ctx, const FrameParams& Pk, int slot) {
+  const uint32_t* src = ctx->h_row_cost + (size_t)slot * ROW_COST_MAX;
+  ctx->row_cost.assign(src, src + std::min<uint32_t>(Pk.tiles_y, ROW_COST_MAX));
+  ctx->row_cost_y0 = Pk.sy;
+  ctx->row_cost_rows = Pk.sh;
+}
+
 void note_flatten_stats(SvrContext* ctx, const Counters& c) {  // device-flattened passes learn these late
   ctx->stats.drawcall_count = (int32_t)c.flat_draws;
   ctx->stats.triangle_count = (int32_t)c.flat_tris;
@@ -578,14 +586,15 @@ int log_slot(SvrContext* ctx, int* slot);
 int retire_ops(SvrContext* ctx, bool blocking);
 int flush_clear(SvrContext* ctx);
 
-int submit_clear(SvrContext* ctx, const SvrContext::LoggedOp& op) {  // every logged operation that is not a pass
+// replaying: the operation is run again by recover_from_overflow (a present then reports 2 instead of 0)
+int submit_clear(SvrContext* ctx, const SvrContext::LoggedOp& op, bool replaying = false) {  // every logged operation that is not a pass
   if (op.fill_kind == 0)
     launch_fill_color(op.clear_rows, op.clear_pixels, op.clear_fmt, op.clear_packed, ctx->d_poison, ctx->stream);
   else if (op.fill_kind == 1)
     launch_background(op.target, op.clear_fmt, op.tw, op.th, op.y_first, op.n_rows, op.bg_effect, op.bg_data, ctx->d_poison, ctx->stream);
   else
     launch_blit(op.target, op.clear_fmt, op.tw, op.th, op.blit_dst, op.blit_w, op.blit_h, op.y_first, op.n_rows, op.blit_fmt, ctx->d_poison,
-                op.blit_rstride, op.blit_roff, op.blit_row_end, op.blit_status, ctx->stream);
+                op.blit_rstride, op.blit_roff, op.blit_row_end, op.blit_status, replaying ? 2u : 0u, ctx->stream);
   HIPCHK(hipGetLastError());
   return SVR_OK;
 }
@@ -599,7 +608,7 @@ int recover_from_overflow(SvrContext* ctx) {
   for (SvrContext::LoggedOp& op : ctx->log) {
     if (!op.is_pass) {
       HIPCHK(hipMemsetAsync(ctx->d_poison, 0, sizeof(uint32_t), ctx->stream));
-      if (int e = submit_clear(ctx, op)) return e;
+      if (int e = submit_clear(ctx, op, true)) return e;
       continue;
     }
     bool done = false;
@@ -628,6 +637,7 @@ int recover_from_overflow(SvrContext* ctx) {
     }
     if (op.P.instrument) note_pass_stats(ctx, op.P, c);
     if (op.P.flatten) note_flatten_stats(ctx, c);
+    note_row_costs(ctx, op.P, op.slot);
     ctx->replayed++;
   }
   HIPCHK(hipMemsetAsync(ctx->d_poison, 0, sizeof(uint32_t), ctx->stream));
@@ -673,13 +683,7 @@ int retire_ops(SvrContext* ctx, bool blocking) {
     }
     if (ctx->log[k].P.instrument) note_pass_stats(ctx, ctx->log[k].P, ctx->h_counters[slot]);
     if (ctx->log[k].P.flatten) note_flatten_stats(ctx, ctx->h_counters[slot]);
-    {  // the tile rows' costs of this pass (posted by its tile kernel before anything else)
-      const FrameParams& Pk = ctx->log[k].P;
-      const uint32_t* src = ctx->h_row_cost + (size_t)slot * ROW_COST_MAX;
-      ctx->row_cost.assign(src, src + std::min<uint32_t>(Pk.tiles_y, ROW_COST_MAX));
-      ctx->row_cost_y0 = Pk.sy;
-      ctx->row_cost_rows = Pk.sh;
-    }
+    note_row_costs(ctx, ctx->log[k].P, slot);
     ctx->log.erase(ctx->log.begin(), ctx->log.begin() + (long)k + 1);
   }
   return SVR_OK;
@@ -1310,7 +1314,7 @@ int svr_read_swapchain(SvrContext* ctx, uint32_t dw, uint32_t dh, int fmt, void*
   if (int e = use_device(ctx)) return e;
   if (int e = finish_pending(ctx)) return e;  // the read-back is a fence
   if (int e = ctx->d_cvt.ensure((size_t)dw * dh * 4)) return e;
-  launch_blit(ctx->color, ctx->fmt, ctx->W, ctx->H, ctx->d_cvt.p, dw, dh, 0, dh, fmt, ctx->d_poison, 1u, 0u, dh, nullptr, ctx->stream);
+  launch_blit(ctx->color, ctx->fmt, ctx->W, ctx->H, ctx->d_cvt.p, dw, dh, 0, dh, fmt, ctx->d_poison, 1u, 0u, dh, nullptr, 0u, ctx->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(dst_host, ctx->d_cvt.p, (size_t)dw * dh * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -3,7 +3,6 @@
 // uses nothing of the renderer but its exported entry points.
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
-#include <pthread.h>
 #include <rccl/rccl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -45,8 +44,32 @@ int fail(int code, const std::string& msg) {
 // shared-memory transport (tests): header + one image per frame slot + one cost profile per rank
 struct ShmHeader {
   std::atomic<uint32_t> ready;
-  pthread_barrier_t barrier;
+  std::atomic<uint32_t> abort;    // a rank failed: nobody waits for it any longer
+  std::atomic<uint32_t> arrived;  // sense-reversing barrier: ranks that reached the current round ...
+  std::atomic<uint32_t> round;    // ... and the round's number
+  uint32_t status[2][64];         // per frame slot and rank: the present's status word (svr_set_present_status)
 };
+
+// barrier over the shared region.  A pthread barrier would leave the peers of a rank that died or bailed out blocked
+// for ever (a test then hangs until its timeout instead of failing with the error): this one gives up when a rank
+// raised the abort flag, or after a minute.
+int shm_barrier(ShmHeader* h, int world) {
+  const uint32_t my_round = h->round.load(std::memory_order_acquire);
+  if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)world) {
+    h->arrived.store(0, std::memory_order_relaxed);
+    h->round.store(my_round + 1, std::memory_order_release);
+    return SVR_OK;
+  }
+  for (uint64_t spin = 0; h->round.load(std::memory_order_acquire) == my_round; spin++) {
+    if (h->abort.load(std::memory_order_acquire)) return fail(SVR_ERR_DEVICE, "shared-memory transport: a peer failed");
+    if (spin > 1200000) {  // 60 s
+      h->abort.store(1, std::memory_order_release);
+      return fail(SVR_ERR_DEVICE, "shared-memory transport: a peer did not arrive within 60 s");
+    }
+    usleep(50);
+  }
+  return SVR_OK;
+}
 
 // Bottleneck-optimal cut of `rows` non-negative costs into `world` consecutive bands: binary search on the
 // largest band's cost over the prefix sums, greedy feasibility (every band takes as many rows as fit).
@@ -97,7 +120,10 @@ std::vector<uint32_t> equal_bounds(uint32_t height, int world) {
 struct SvrDist {
   SvrContext* ctx = nullptr;
   int transport = SVR_DIST_RCCL, rank = 0, world = 1, fmt = SVR_SWAPCHAIN_B8G8R8A8;
-  uint32_t W = 0, H = 0, band = 0;  // band: rows of an equal band (the images are padded to band * world rows)
+  uint32_t W = 0, H = 0, band = 0;  // band: rows of an equal band (the images are padded to band * world rows, at least)
+  uint32_t rows_padded = 0;         // ... and to whole groups of `world` tile rows (the interleaved partition's all-gathers)
+  int partition = SVR_DIST_BANDS;   // what the next begin_frame uses
+  uint32_t replays = 0;             // frames exchanged a second time because a rank's present had been void
   std::vector<uint32_t> bounds;
   hipStream_t render = nullptr, comm = nullptr;
   static const int SLOTS = 2;
@@ -107,6 +133,9 @@ struct SvrDist {
     uint8_t* image = nullptr;   // the swapchain image that travels
     hipEvent_t rendered = nullptr, exchanged = nullptr;
     std::vector<uint32_t> bounds;  // the partition this slot's frame in flight was rendered with
+    int partition = SVR_DIST_BANDS;
+    uint32_t* status = nullptr;    // device, [world]: every rank's present status of this frame (own word: [rank])
+    uint32_t* h_status = nullptr;  // pinned, [world]: the same after the exchange
     bool in_flight = false;
   } slots[SLOTS];
   int cur = -1;                 // slot between begin_frame and end_frame
@@ -125,49 +154,99 @@ struct SvrDist {
 
 namespace {
 
-size_t padded_rows(const SvrDist* d) { return (size_t)d->band * (size_t)d->world; }
+size_t padded_rows(const SvrDist* d) { return d->rows_padded; }
 size_t image_bytes(const SvrDist* d) { return padded_rows(d) * d->W * 4; }
+
+// rows [first, first + n) a rank contributes to a frame: one run per band, one per tile row when they are interleaved
+struct RowRun {
+  uint32_t first, n;
+};
+std::vector<RowRun> runs_of(const SvrDist* d, const SvrDist::Slot& s, int rank) {
+  std::vector<RowRun> out;
+  if (s.partition == SVR_DIST_INTERLEAVED) {
+    for (uint32_t t = (uint32_t)rank; t * 32u < d->H; t += (uint32_t)d->world) out.push_back({t * 32u, std::min(32u, d->H - t * 32u)});
+  } else {
+    const uint32_t y0 = s.bounds[(size_t)rank], n = s.bounds[(size_t)rank + 1] - y0;
+    if (n) out.push_back({y0, n});
+  }
+  return out;
+}
 
 int exchange(SvrDist* d, SvrDist::Slot& s) {
   const size_t row_bytes = (size_t)d->W * 4;
   const std::vector<uint32_t>& b = s.bounds;
   if (d->transport == SVR_DIST_RCCL) {  // (also with one rank: the same calls, trivially)
     HIPCHK(hipStreamWaitEvent(d->comm, s.rendered, 0));
-    if (b == equal_bounds(d->H, d->world)) {  // one in-place all-gather of equal chunks (the image is padded to band * world rows)
+    // A failing call inside a group must not leave the group open (every later RCCL call of this thread would queue
+    // into it): the first error is kept, the group is always ended.
+    ncclResult_t first_err = ncclSuccess;
+    const char* what = "";
+    auto note = [&](ncclResult_t r, const char* w) {
+      if (r != ncclSuccess && first_err == ncclSuccess) {
+        first_err = r;
+        what = w;
+      }
+    };
+    if (s.partition == SVR_DIST_INTERLEAVED) {
+      // tile row t belongs to rank t % world: every group of `world` consecutive tile rows is one in-place all-gather
+      // of 32-row chunks (the image is padded to whole groups), all of them in one RCCL group = one launch
+      const size_t chunk = 32 * row_bytes;
+      note(ncclGroupStart(), "ncclGroupStart");
+      for (size_t g = 0; g * (size_t)d->world * 32 < d->H; g++) {
+        uint8_t* base = s.image + g * (size_t)d->world * chunk;
+        note(ncclAllGather(base + (size_t)d->rank * chunk, base, chunk, ncclUint8, d->comm_rccl, d->comm), "ncclAllGather");
+      }
+      note(ncclGroupEnd(), "ncclGroupEnd");
+    } else if (b == equal_bounds(d->H, d->world)) {  // one in-place all-gather of equal chunks (the image is padded to band * world rows)
       const size_t n = (size_t)d->band * row_bytes;
-      NCCLCHK(ncclAllGather(s.image + (size_t)d->rank * n, s.image, n, ncclUint8, d->comm_rccl, d->comm));
+      note(ncclAllGather(s.image + (size_t)d->rank * n, s.image, n, ncclUint8, d->comm_rccl, d->comm), "ncclAllGather");
     } else {  // unequal bands: every band straight into its rows of every peer's image, one group
-      NCCLCHK(ncclGroupStart());
+      note(ncclGroupStart(), "ncclGroupStart");
       const size_t mine = (size_t)(b[(size_t)d->rank + 1] - b[(size_t)d->rank]) * row_bytes;
       for (int peer = 0; peer < d->world; peer++) {
         if (peer == d->rank) continue;
-        if (mine) NCCLCHK(ncclSend(s.image + (size_t)b[(size_t)d->rank] * row_bytes, mine, ncclUint8, peer, d->comm_rccl, d->comm));
+        if (mine) note(ncclSend(s.image + (size_t)b[(size_t)d->rank] * row_bytes, mine, ncclUint8, peer, d->comm_rccl, d->comm), "ncclSend");
         const size_t theirs = (size_t)(b[(size_t)peer + 1] - b[(size_t)peer]) * row_bytes;
-        if (theirs) NCCLCHK(ncclRecv(s.image + (size_t)b[(size_t)peer] * row_bytes, theirs, ncclUint8, peer, d->comm_rccl, d->comm));
+        if (theirs) note(ncclRecv(s.image + (size_t)b[(size_t)peer] * row_bytes, theirs, ncclUint8, peer, d->comm_rccl, d->comm), "ncclRecv");
       }
-      NCCLCHK(ncclGroupEnd());
+      note(ncclGroupEnd(), "ncclGroupEnd");
     }
+    // every rank's present status travels behind the rows: a rank whose pass overflowed sent stale rows, and everybody
+    // learns it with the frame (svr_dist_wait_frame)
+    note(ncclAllGather(s.status + d->rank, s.status, 1, ncclUint32, d->comm_rccl, d->comm), "ncclAllGather(status)");
+    if (first_err != ncclSuccess) return fail(SVR_ERR_DEVICE, std::string(what) + ": " + ncclGetErrorString(first_err));
+    HIPCHK(hipMemcpyAsync(s.h_status, s.status, (size_t)d->world * 4, hipMemcpyDeviceToHost, d->comm));
     HIPCHK(hipEventRecord(s.exchanged, d->comm));
     return SVR_OK;
   }
   if (d->world == 1) {
+    HIPCHK(hipMemcpyAsync(s.h_status, s.status, 4, hipMemcpyDeviceToHost, d->render));
     HIPCHK(hipEventRecord(s.exchanged, d->render));
     return SVR_OK;
   }
-  // shared memory (tests): blocking.  One barrier per exchange is enough: a rank enters the next exchange only
+  // shared memory (tests): blocking.  One barrier behind the reads is enough: a rank enters the next exchange only
   // after it has read everything it wanted from this one.
   const int slot = (int)(&s - d->slots);
   uint8_t* shared = d->shm_images + (size_t)slot * image_bytes(d);
-  HIPCHK(hipEventSynchronize(s.rendered));
-  const size_t y0 = b[(size_t)d->rank], rows = b[(size_t)d->rank + 1] - y0;
-  if (rows) HIPCHK(hipMemcpy(shared + y0 * row_bytes, s.image + y0 * row_bytes, rows * row_bytes, hipMemcpyDeviceToHost));
-  pthread_barrier_wait(&d->hdr->barrier);
+  auto bail = [&](int code) {  // the peers must not wait for a rank that gave up
+    d->hdr->abort.store(1, std::memory_order_release);
+    return code;
+  };
+  if (hipEventSynchronize(s.rendered) != hipSuccess) return bail(fail(SVR_ERR_DEVICE, "hipEventSynchronize(rendered)"));
+  for (const RowRun& r : runs_of(d, s, d->rank))
+    if (hipMemcpy(shared + r.first * row_bytes, s.image + r.first * row_bytes, r.n * row_bytes, hipMemcpyDeviceToHost) != hipSuccess)
+      return bail(fail(SVR_ERR_DEVICE, "hipMemcpy of the band to the shared image"));
+  if (hipMemcpy(&d->hdr->status[slot][d->rank], s.status + d->rank, 4, hipMemcpyDeviceToHost) != hipSuccess)
+    return bail(fail(SVR_ERR_DEVICE, "hipMemcpy of the present status"));
+  if (int e = shm_barrier(d->hdr, d->world)) return e;
   for (int peer = 0; peer < d->world; peer++) {
+    s.h_status[peer] = d->hdr->status[slot][peer];
     if (peer == d->rank) continue;
-    const size_t p0 = b[(size_t)peer], prow = b[(size_t)peer + 1] - p0;
-    if (prow) HIPCHK(hipMemcpy(s.image + p0 * row_bytes, shared + p0 * row_bytes, prow * row_bytes, hipMemcpyHostToDevice));
+    for (const RowRun& r : runs_of(d, s, peer))
+      if (hipMemcpy(s.image + r.first * row_bytes, shared + r.first * row_bytes, r.n * row_bytes, hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(SVR_ERR_DEVICE, "hipMemcpy of a peer's band"));
   }
-  pthread_barrier_wait(&d->hdr->barrier);  // nobody overwrites the shared image while a peer still reads it
+  if (int e = shm_barrier(d->hdr, d->world)) return e;  // nobody overwrites the shared image while a peer still reads it
   HIPCHK(hipEventRecord(s.exchanged, d->comm));
   return SVR_OK;
 }
@@ -210,6 +289,10 @@ int svr_dist_create(SvrContext* ctx, int transport, const uint8_t id[SVR_DIST_ID
   d->H = height;
   d->fmt = swapchain_format;
   d->band = (height + (uint32_t)world - 1) / (uint32_t)world;
+  {
+    const uint32_t tile_rows = (height + 31u) / 32u, groups = (tile_rows + (uint32_t)world - 1) / (uint32_t)world;
+    d->rows_padded = std::max(d->band * (uint32_t)world, groups * (uint32_t)world * 32u);
+  }
   d->bounds = equal_bounds(height, world);
   auto bail = [&](int code) {
     svr_dist_destroy(d);
@@ -230,6 +313,10 @@ int svr_dist_create(SvrContext* ctx, int transport, const uint8_t id[SVR_DIST_ID
     TRY_HIP(hipMemset(s.color, 0, rows * width * 8));
     TRY_HIP(hipMemset(s.depth, 0, rows * width * 4));
     TRY_HIP(hipMemset(s.image, 0, rows * width * 4));
+    TRY_HIP(hipMalloc((void**)&s.status, 64 * sizeof(uint32_t)));
+    TRY_HIP(hipMemset(s.status, 0, 64 * sizeof(uint32_t)));
+    TRY_HIP(hipHostMalloc((void**)&s.h_status, 64 * sizeof(uint32_t), hipHostMallocDefault));
+    std::memset(s.h_status, 0, 64 * sizeof(uint32_t));
     TRY_HIP(hipEventCreateWithFlags(&s.rendered, hipEventDisableTiming));
     TRY_HIP(hipEventCreateWithFlags(&s.exchanged, hipEventDisableTiming));
   }
@@ -267,19 +354,15 @@ int svr_dist_create(SvrContext* ctx, int transport, const uint8_t id[SVR_DIST_ID
     d->hdr = reinterpret_cast<ShmHeader*>(d->shm);
     d->shm_images = reinterpret_cast<uint8_t*>(d->shm) + 4096;
     d->shm_profiles = reinterpret_cast<uint64_t*>(d->shm_images + (size_t)SvrDist::SLOTS * image_bytes(d));
-    if (creator) {
-      pthread_barrierattr_t attr;
-      pthread_barrierattr_init(&attr);
-      pthread_barrierattr_setpshared(&attr, PTHREAD_PROCESS_SHARED);
-      pthread_barrier_init(&d->hdr->barrier, &attr, (unsigned)world);
-      pthread_barrierattr_destroy(&attr);
+    if (creator) {  // (ftruncate zeroed the region: abort, arrived, round and the status words start at 0)
       d->hdr->ready.store(1u, std::memory_order_release);
     } else {
       for (int spin = 0; spin < 200000 && d->hdr->ready.load(std::memory_order_acquire) == 0u; spin++) usleep(50);
       if (d->hdr->ready.load(std::memory_order_acquire) == 0u) return bail(fail(SVR_ERR_DEVICE, "svr_dist_create: shared region never became ready"));
     }
-    pthread_barrier_wait(&d->hdr->barrier);  // everyone has mapped it: the name can go
+    const int arrived = shm_barrier(d->hdr, world);  // everyone has mapped it: the name can go
     if (creator) shm_unlink(d->shm_name.c_str());
+    if (arrived != SVR_OK) return bail(arrived);
   }
 #undef TRY_HIP
   *out = d;
@@ -292,6 +375,8 @@ void svr_dist_destroy(SvrDist* d) {
     (void)svr_sync(d->ctx);
     (void)svr_bind_targets(d->ctx, nullptr, nullptr);
     (void)svr_set_scissor(d->ctx, 0, 0, d->W, d->H);
+    (void)svr_set_row_interleave(d->ctx, 1, 0);
+    (void)svr_set_present_status(d->ctx, nullptr);
     (void)svr_set_stream(d->ctx, nullptr);
   }
   if (d->comm) (void)hipStreamSynchronize(d->comm);
@@ -300,6 +385,8 @@ void svr_dist_destroy(SvrDist* d) {
     if (s.color) (void)hipFree(s.color);
     if (s.depth) (void)hipFree(s.depth);
     if (s.image) (void)hipFree(s.image);
+    if (s.status) (void)hipFree(s.status);
+    if (s.h_status) (void)hipHostFree(s.h_status);
     if (s.rendered) (void)hipEventDestroy(s.rendered);
     if (s.exchanged) (void)hipEventDestroy(s.exchanged);
   }
@@ -337,7 +424,7 @@ int svr_dist_band(SvrDist* d, uint32_t* first_row, uint32_t* rows) {
 int svr_dist_rebalance(SvrDist* d, float measured_gpu_ms, int* changed) {
   if (!d) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_dist_rebalance: null argument");
   if (changed) *changed = 0;
-  if (d->world == 1) return SVR_OK;
+  if (d->world == 1 || d->partition == SVR_DIST_INTERLEAVED) return SVR_OK;  // interleaved rows are balanced by construction
   // this rank's tile-row costs, spread over the pixel rows they cover (x1024 keeps the remainders), then scaled so
   // that the band adds up to its measured time in nanoseconds
   std::vector<uint32_t> costs(512);
@@ -364,10 +451,10 @@ int svr_dist_rebalance(SvrDist* d, float measured_gpu_ms, int* changed) {
     HIPCHK(hipStreamSynchronize(d->comm));
   } else {
     std::memcpy(d->shm_profiles + (size_t)d->rank * d->H, mine.data(), (size_t)d->H * 8);
-    pthread_barrier_wait(&d->hdr->barrier);
+    if (int e = shm_barrier(d->hdr, d->world)) return e;
     for (int r = 0; r < d->world; r++)
       for (uint32_t y = 0; y < d->H; y++) profile[y] += d->shm_profiles[(size_t)r * d->H + y];
-    pthread_barrier_wait(&d->hdr->barrier);
+    if (int e = shm_barrier(d->hdr, d->world)) return e;
   }
   uint64_t sum = 0, covered = 0;
   for (uint64_t v : profile) {
@@ -386,6 +473,48 @@ int svr_dist_rebalance(SvrDist* d, float measured_gpu_ms, int* changed) {
   return SVR_OK;
 }
 
+int svr_dist_set_partition(SvrDist* d, int partition) {
+  if (!d) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_dist_set_partition: null argument");
+  if (partition != SVR_DIST_BANDS && partition != SVR_DIST_INTERLEAVED) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_dist_set_partition: unknown partition");
+  d->partition = partition;
+  return SVR_OK;
+}
+
+int svr_dist_get_partition(SvrDist* d, int* partition) {
+  if (!d || !partition) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_dist_get_partition: null argument");
+  *partition = d->partition;
+  return SVR_OK;
+}
+
+int svr_dist_pick_partition(SvrDist* d, float bands_ms, float interleaved_ms, int* picked) {
+  if (!d) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_dist_pick_partition: null argument");
+  // the frame is as slow as its slowest rank: max over the ranks of either time, then the smaller of the two
+  uint64_t mine[2] = {(uint64_t)(std::max(bands_ms, 0.f) * 1e6), (uint64_t)(std::max(interleaved_ms, 0.f) * 1e6)}, all[2] = {mine[0], mine[1]};
+  if (d->world > 1) {
+    if (d->transport == SVR_DIST_RCCL) {
+      HIPCHK(hipMemcpyAsync(d->d_profile, mine, 16, hipMemcpyHostToDevice, d->comm));
+      NCCLCHK(ncclAllReduce(d->d_profile, d->d_profile, 2, ncclUint64, ncclMax, d->comm_rccl, d->comm));
+      HIPCHK(hipMemcpyAsync(all, d->d_profile, 16, hipMemcpyDeviceToHost, d->comm));
+      HIPCHK(hipStreamSynchronize(d->comm));
+    } else {
+      std::memcpy(d->shm_profiles + (size_t)d->rank * d->H, mine, 16);
+      if (int e = shm_barrier(d->hdr, d->world)) return e;
+      for (int r = 0; r < d->world; r++)
+        for (int k = 0; k < 2; k++) all[k] = std::max(all[k], d->shm_profiles[(size_t)r * d->H + (size_t)k]);
+      if (int e = shm_barrier(d->hdr, d->world)) return e;
+    }
+  }
+  d->partition = all[1] < all[0] ? SVR_DIST_INTERLEAVED : SVR_DIST_BANDS;
+  if (picked) *picked = d->partition;
+  return SVR_OK;
+}
+
+int svr_dist_replays(SvrDist* d, uint32_t* n) {
+  if (!d || !n) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_dist_replays: null argument");
+  *n = d->replays;
+  return SVR_OK;
+}
+
 int svr_dist_begin_frame(SvrDist* d) {
   if (!d) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_dist_begin_frame: null argument");
   if (d->cur >= 0) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_dist_begin_frame: the previous frame was not ended");
@@ -398,9 +527,16 @@ int svr_dist_begin_frame(SvrDist* d) {
   if (slot < 0) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_dist_begin_frame: both frame slots are in flight (svr_dist_wait_frame first)");
   SvrDist::Slot& s = d->slots[slot];
   s.bounds = d->bounds;
+  s.partition = d->partition;
   SVRCHK(svr_bind_targets(d->ctx, s.color, s.depth));
-  const uint32_t y0 = s.bounds[(size_t)d->rank], rows = s.bounds[(size_t)d->rank + 1] - y0;
-  if (rows) SVRCHK(svr_set_scissor(d->ctx, 0, y0, d->W, rows));
+  if (s.partition == SVR_DIST_INTERLEAVED) {
+    SVRCHK(svr_set_scissor(d->ctx, 0, 0, d->W, d->H));
+    SVRCHK(svr_set_row_interleave(d->ctx, (uint32_t)d->world, (uint32_t)d->rank));
+  } else {
+    SVRCHK(svr_set_row_interleave(d->ctx, 1, 0));
+    const uint32_t y0 = s.bounds[(size_t)d->rank], rows = s.bounds[(size_t)d->rank + 1] - y0;
+    if (rows) SVRCHK(svr_set_scissor(d->ctx, 0, y0, d->W, rows));
+  }
   d->cur = slot;
   return SVR_OK;
 }
@@ -409,9 +545,13 @@ int svr_dist_end_frame(SvrDist* d) {
   if (!d) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_dist_end_frame: null argument");
   if (d->cur < 0) return fail(SVR_ERR_INVALID_ARGUMENT, "svr_dist_end_frame: no frame was begun");
   SvrDist::Slot& s = d->slots[d->cur];
-  const uint32_t rows = s.bounds[(size_t)d->rank + 1] - s.bounds[(size_t)d->rank];
-  // vkutil::copy_image of this rank's rows: identity extent = the scissor's rows (include/svr.h)
-  if (rows) SVRCHK(svr_copy_to_swapchain(d->ctx, s.image, d->W, d->H, d->fmt));
+  // vkutil::copy_image of this rank's rows: identity extent = the scissor's rows / the context's own tile rows
+  // (include/svr.h); the present reports into the slot's status word whether it was carried out
+  if (!runs_of(d, s, d->rank).empty()) {
+    SVRCHK(svr_set_present_status(d->ctx, s.status + d->rank));
+    SVRCHK(svr_copy_to_swapchain(d->ctx, s.image, d->W, d->H, d->fmt));
+    SVRCHK(svr_set_present_status(d->ctx, nullptr));
+  }
   HIPCHK(hipEventRecord(s.rendered, d->render));
   if (int e = exchange(d, s)) return e;
   s.in_flight = true;
@@ -427,6 +567,24 @@ int svr_dist_wait_frame(SvrDist* d, const void** image_dev) {
   d->fifo.erase(d->fifo.begin());
   SvrDist::Slot& s = d->slots[slot];
   HIPCHK(hipEventSynchronize(s.exchanged));
+  // A presented image is a finished one (src/vk_engine.cpp:1226, 1332).  The renderer replays a pass that overflowed
+  // its queues — and the present behind it — but only when it next looks (include/svr.h, svr_set_present_status), and
+  // it knows nothing of the exchange: the rows that travelled were the slot's old ones.  The status words travelled
+  // with them, so every rank sees the same thing here and the repair is collective without a message of its own:
+  // fence (the owner replays; the others only wait for their own work), then exchange the slot again.  (A word of 2:
+  // the replay ran by itself — any svr_* call may find the overflow — possibly under the exchange: same repair.)
+  for (int attempt = 0;; attempt++) {
+    bool stale = false;
+    for (int r = 0; r < d->world; r++) stale |= s.h_status[r] != 0u;
+    if (!stale) break;
+    if (attempt == 4) return fail(SVR_ERR_OVERFLOW, "svr_dist_wait_frame: a rank's present stayed void after four exchanges");
+    SVRCHK(svr_sync(d->ctx));
+    if (s.h_status[d->rank]) HIPCHK(hipMemsetAsync(s.status + d->rank, 0, 4, d->render));  // the replay's present left a 2
+    HIPCHK(hipEventRecord(s.rendered, d->render));
+    if (int e = exchange(d, s)) return e;
+    HIPCHK(hipEventSynchronize(s.exchanged));
+    d->replays++;
+  }
   // the render stream may reuse the slot once the exchange has read it
   HIPCHK(hipStreamWaitEvent(d->render, s.exchanged, 0));
   s.in_flight = false;

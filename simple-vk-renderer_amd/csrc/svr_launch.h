@@ -33,10 +33,10 @@ void launch_fill_color(void* color, uint32_t n_pixels, int color_format, uint64_
 void launch_background(void* color, int color_format, uint32_t W, uint32_t H, uint32_t y_first, uint32_t n_rows, int effect,
                        const float data[16], const uint32_t* poison, hipStream_t s);
 // rstride / roff / row_end: the interleaved tile rows of svr_set_row_interleave (1, 0, row_first + n_rows: all rows);
-// status: device word that receives 1 when the blit was void (poison), else 0 (may be null)
+// status: device word that receives 1 when the blit was void (poison), else status_ok (may be null)
 void launch_blit(const void* color, int color_format, uint32_t W, uint32_t H, void* dst, uint32_t dw, uint32_t dh, uint32_t row_first,
                  uint32_t n_rows, int dst_format, const uint32_t* poison, uint32_t rstride, uint32_t roff, uint32_t row_end, uint32_t* status,
-                 hipStream_t s);
+                 uint32_t status_ok, hipStream_t s);
 void launch_downsample(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t* dst, uint32_t dw, uint32_t dh,
                        hipStream_t s);
 void launch_rgba16f_to_rgba8(const void* src, void* dst, uint32_t n_pixels, hipStream_t s);

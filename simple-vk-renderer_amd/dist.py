@@ -26,6 +26,18 @@ profile).  Unequal bands travel as one batch of point-to-point sends and receive
 ncclSend/ncclRecv under RCCL: every band goes straight into its rows of every peer's frame, no padding,
 no un-permute pass); equal bands keep the single all-gather.  xGMI is point-to-point (7 links per GPU),
 so either way a band crosses each link once.
+
+The other partition SURVEY 8e names — interleaved tile rows, rank r owning the 32-row tile rows t with
+t % world == r (svr_set_row_interleave) — is balanced by construction (deep and shallow regions are dealt out
+evenly) at the price of every rank running the whole scene's vertex stage.  Its rows travel as one in-place
+all-gather per `world` consecutive tile rows (coalesced into one launch under RCCL).  BandPlan.pick chooses
+between the two from measured times, collectively.
+
+A presented image is a finished one (src/vk_engine.cpp:1226, 1332): a pass that overflows the renderer's queues is
+void and replayed later, the present behind it too, but the exchange is this module's own stream work.  Every
+present therefore reports into a status word (svr_set_present_status) that is gathered behind the rows; a slot
+whose gathered words are not all 0 is fenced and exchanged again before it is reused or handed out — on every rank
+alike, because every rank reads the same words.
 """
 import math
 
@@ -38,6 +50,18 @@ def band_rows(height, rank, world):
     y0 = min(rank * band, height)
     y1 = min(y0 + band, height)
     return y0, y1 - y0, band
+
+
+def interleaved_rows(height, rank, world):
+    """[(first_row, n_rows)] of the 32-row tile rows t with t % world == rank"""
+    return [(t * 32, min(32, height - t * 32)) for t in range(rank, (height + 31) // 32, world)]
+
+
+def padded_height(height, world):
+    """rows of the buffers that travel: whole equal bands AND whole groups of `world` tile rows"""
+    band = int(math.ceil(height / world))
+    groups = int(math.ceil(((height + 31) // 32) / world))
+    return max(band * world, groups * world * 32)
 
 
 def equal_bounds(height, world):
@@ -83,6 +107,7 @@ class BandPlan:
     def __init__(self, height, world, balanced=True, min_gain=0.2):
         self.height, self.world, self.balanced = height, world, balanced
         self.bounds = equal_bounds(height, world)
+        self.partition = "bands"  # or "interleaved"
         self.updates = 0
         # Unequal bands cost the HOST more per frame than equal ones (a batch of point-to-point operations instead of
         # one all-gather: tens of microseconds from Python), so a cost-balanced cut is adopted only where it shortens
@@ -137,12 +162,22 @@ class BandPlan:
         self.updates += 1
         return changed
 
+    def pick(self, torch, dist, device, bands_ms, interleaved_ms):
+        """Collective: every rank hands in what a frame cost it under either partition; the frame is as slow as its
+        slowest rank, so the partition with the smaller maximum is taken on every rank alike.  Returns its name."""
+        t = torch.tensor([float(bands_ms), float(interleaved_ms)], dtype=torch.float64, device=device)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        b, i = (float(v) for v in t.tolist())
+        self.partition = "interleaved" if i < b else "bands"
+        return self.partition
+
     def rebalance(self, torch, dist, renderer, device, measured_ms=None):
         """Collective (every rank calls it at the same frame): re-cut the frame from the ranks' latest row costs,
         each band's costs scaled to its measured GPU time when the caller has one (all ranks or none) — the tile stage's
         (SvrStats.tile_ms): geometry and binning are the same for every band and would only tilt the rows' costs.
         Returns True when the boundaries changed."""
-        if not self.balanced or self.world == 1:
+        if not self.balanced or self.world == 1 or self.partition == "interleaved":  # (balanced by construction)
             return False
         costs, y0, rows = renderer.row_costs()
         mine = self.scale_to(self.spread(costs, y0, rows, self.height), measured_ms)
@@ -161,7 +196,7 @@ class ShardedFrame:
         self.W, self.H = renderer.width, renderer.height
         self.plan = plan if plan is not None else BandPlan(self.H, world, balanced=False)
         band = int(math.ceil(self.H / world))
-        hp = band * world  # padded height: with equal bands every rank's chunk of the all-gather has `band` rows
+        hp = padded_height(self.H, world)  # with equal bands every rank's chunk of the all-gather has `band` rows
         self.band = band
         cdtype = torch.float16 if color_format == abi.COLOR_RGBA16F else torch.uint8
         self.color = torch.zeros((hp, self.W, 4), dtype=cdtype, device=device)
@@ -174,18 +209,34 @@ class ShardedFrame:
         self.bound = bind
         self.work = None
         self._dist = None
-        self._replays = 0  # renderer's replayed_passes as of the last finish()
         self._ops, self._ops_key = [], None
         self.y0, self.rows = self.plan.rows_of(rank)
         self.bounds = list(self.plan.bounds)  # the partition this slot's frame in flight was rendered with
+        self.partition = self.plan.partition
+        # every rank's present status of the frame in flight (svr_set_present_status; own word: [rank]) and its
+        # host copy, made behind the exchange on a side stream so that reading it never stalls the render stream
+        self.status = torch.zeros(world, dtype=torch.int32, device=device)
+        self.on_gpu = self.status.is_cuda
+        self.h_status = torch.zeros(world, dtype=torch.int32).pin_memory() if self.on_gpu else self.status
+        self.side = torch.cuda.Stream(device=device) if self.on_gpu else None
+        self.status_ready = torch.cuda.Event() if self.on_gpu else None
+        self.exchanged_again = 0  # frames this slot had to exchange a second time
 
     def begin(self):
         """Make this slot the render target; waits (on the stream) for the slot's previous exchange."""
         self._wait()
+        self._repair()  # the frame this slot held is final before the slot is used again
         self.bounds = list(self.plan.bounds)
-        self.y0, self.rows = self.bounds[self.rank], self.bounds[self.rank + 1] - self.bounds[self.rank]
+        self.partition = self.plan.partition
         if self.bound:
             self.r.bind_targets(self.color.data_ptr(), self.depth.data_ptr())
+        if self.partition == "interleaved":
+            self.y0, self.rows = 0, sum(n for _, n in interleaved_rows(self.H, self.rank, self.world))
+            self.r.set_scissor(0, 0, self.W, self.H)
+            self.r.set_row_interleave(self.world, self.rank)
+            return
+        self.y0, self.rows = self.bounds[self.rank], self.bounds[self.rank + 1] - self.bounds[self.rank]
+        self.r.set_row_interleave(1, 0)
         if self.rows > 0:
             self.r.set_scissor(0, self.y0, self.W, self.rows)
 
@@ -196,11 +247,41 @@ class ShardedFrame:
             self.work = None
 
     def _exchange(self, dist, async_op):
-        """every rank's rows -> every rank's frame, in place"""
+        """every rank's rows -> every rank's frame, in place; every rank's status word behind them"""
+        works = self._exchange_rows(dist, async_op)
+        if self.present:
+            h = dist.all_gather_into_tensor(self.status, self.status[self.rank:self.rank + 1], async_op=async_op)
+            if async_op:
+                works = (works if isinstance(works, list) else ([works] if works is not None else [])) + [h]
+            if self.on_gpu:  # host copy of the words on the side stream, behind the exchange
+                self.side.wait_stream(self.torch.cuda.current_stream(self.status.device))
+                with self.torch.cuda.stream(self.side):
+                    for w in (works or []):
+                        w.wait()
+                    self.h_status.copy_(self.status, non_blocking=True)
+                    self.status_ready.record()
+        return works if async_op else None
+
+    def _exchange_rows(self, dist, async_op):
+        if self.partition == "interleaved":
+            # tile row t belongs to rank t % world: every group of `world` consecutive tile rows is one in-place
+            # all-gather of 32-row chunks (the buffers are padded to whole groups); RCCL: coalesced into one launch
+            chunk = 32 * self.W * self.image_t.shape[2] * self.image_t.element_size()
+            flat = self.image_t.view(self.torch.uint8).view(-1) if self.image_t.dtype != self.torch.uint8 else self.flat
+            groups = int(math.ceil(((self.H + 31) // 32) / self.world))
+            parts = [(flat[g * self.world * chunk:(g + 1) * self.world * chunk],
+                      flat[(g * self.world + self.rank) * chunk:(g * self.world + self.rank + 1) * chunk]) for g in range(groups)]
+            if self.on_gpu and dist.get_backend() == "nccl":
+                with dist._coalescing_manager(device=self.image_t.device, async_ops=async_op) as cm:
+                    for out, mine in parts:
+                        dist.all_gather_into_tensor(out, mine)
+                return [cm] if async_op else None
+            works = [dist.all_gather_into_tensor(out, mine, async_op=async_op) for out, mine in parts]
+            return works if async_op else None
         equal = self.bounds == equal_bounds(self.H, self.world)
         if equal:
             n = self.band * self.W * 4
-            h = dist.all_gather_into_tensor(self.flat, self.flat[self.rank * n:(self.rank + 1) * n], async_op=async_op)
+            h = dist.all_gather_into_tensor(self.flat[:self.world * n], self.flat[self.rank * n:(self.rank + 1) * n], async_op=async_op)
             return h if async_op else None
         if self.image_t.is_cuda and dist.get_backend() == "gloo":
             # rehearsals on a one-GPU box (SVR_BENCH_REHEARSE): gloo moves device tensors only through its collectives,
@@ -239,40 +320,47 @@ class ShardedFrame:
     def gather(self, dist, async_op=True):
         """Exchange the finished bands; in place (a rank's band is its rows of the full frame)."""
         if self.present:
-            if self.rows > 0:  # vkutil::copy_image of this rank's rows (the scissor is still the band)
+            if self.rows > 0:  # vkutil::copy_image of this rank's rows (scissor / row set are still the frame's)
+                self.r.set_present_status(self.status[self.rank:].data_ptr())
                 self.r.copy_to_swapchain(self.swapchain.data_ptr(), self.W, self.H, 0)
+                self.r.set_present_status(0)
         elif not self.bound:  # test path (CPU oracle owns its targets): copy the band out first
             col = self.r.read_color()
             t = self.torch.from_numpy(col.view(np.float16) if col.dtype == np.uint16 else col)
-            self.color[self.y0:self.y0 + self.rows].copy_(t[self.y0:self.y0 + self.rows])
+            runs = interleaved_rows(self.H, self.rank, self.world) if self.partition == "interleaved" else [(self.y0, self.rows)]
+            for y, n in runs:
+                self.color[y:y + n].copy_(t[y:y + n])
         if self.world == 1:
             return
         self._dist = dist
         self.work = self._exchange(dist, async_op)
 
-    def _replayed_passes(self):
-        try:
-            return int(self.r.get_stats().replayed_passes)  # fences the renderer
-        except AttributeError:  # the CPU oracle (tests) has no queues to overflow
-            return 0
+    def _repair(self):
+        """The frame this slot last exchanged, made final: if any rank's present of it was void (1) or rerun by the
+        replay, possibly under the exchange (2), fence the renderer — the owner's replay runs there — and exchange the
+        slot again.  Collective without a message of its own: every rank reads the same gathered words."""
+        if self.world == 1 or not self.present or self._dist is None:
+            return
+        for attempt in range(5):
+            if self.on_gpu:
+                self.status_ready.synchronize()
+            words = self.h_status.tolist()
+            if not any(words):
+                return
+            if attempt == 4:
+                raise RuntimeError("a rank's present stayed void after four exchanges")
+            self.r.sync()
+            if words[self.rank]:
+                self.status[self.rank] = 0
+            self._exchange(self._dist, False)
+            self.exchanged_again += 1
+            if self.on_gpu:
+                self.torch.cuda.current_stream(self.status.device).synchronize()
 
     def finish(self):
-        """Wait for the slot's exchange.  The exchange is the caller's own stream work, which the renderer's
-        overflow replay (svr_api.hip, operation log) does not know about: if a pass of this frame was
-        replayed after the band had been sent, send the band again."""
+        """Wait for the slot's exchange and make its frame final (see _repair)."""
         self._wait()
-        if self.world > 1 and self.bound and self._dist is not None:
-            now = self._replayed_passes()  # a fence, like this whole call
-            flag = self.torch.tensor([1 if now != self._replays else 0], dtype=self.torch.int32, device=self.color.device)
-            self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX)  # the re-send is a collective: all ranks or none
-            self._replays = now
-            if int(flag.item()):
-                if self.present and self.rows > 0:  # the replayed rows have to be presented again first
-                    self.r.bind_targets(self.color.data_ptr(), self.depth.data_ptr())
-                    self.r.set_scissor(0, self.y0, self.W, self.rows)
-                    self.r.copy_to_swapchain(self.swapchain.data_ptr(), self.W, self.H, 0)
-                    self.r.sync()
-                self._exchange(self._dist, False)
+        self._repair()
 
     def image(self):
         """The gathered frame without the padding rows (B8G8R8A8 swapchain bytes, or the colour target)."""

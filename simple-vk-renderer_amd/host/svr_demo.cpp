@@ -10,6 +10,7 @@
 //
 // Scene: a three-level node hierarchy of cubes (exercises Node::refresh_transform's parent_matrix quirk and
 // MeshNode::Draw's world*top order) with an opaque default material and a Transparent checker one.
+#include <csignal>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -56,9 +57,12 @@ static void dump(const std::string& path, const T* p, size_t n) {
   f.write(reinterpret_cast<const char*>(p), (std::streamsize)(n * sizeof(T)));
 }
 
+static std::vector<pid_t> g_kids;  // rank 0 of --ranks N: the other ranks' processes
+static bool g_exit_ok = false;
+
 int main(int argc, char** argv) {
   std::string lib, prefix, gltf, png, dist_lib, transport = "shm", bounds_arg;
-  int ranks = 1, rebalance = 0;
+  int ranks = 1, rebalance = 0, queue_caps = 0, partition = 0, pick_partition = 0;
   uint32_t w = 160, h = 90;
   int frames = 2, background = 0;
   float cam[5] = {0, 0, 0, 0, 0};  // position, pitch, yaw
@@ -72,6 +76,9 @@ int main(int argc, char** argv) {
     else if (a == "--transport") transport = argv[i + 1];
     else if (a == "--bounds") bounds_arg = argv[i + 1];
     else if (a == "--rebalance") rebalance = atoi(argv[i + 1]);
+    else if (a == "--queue-caps") queue_caps = atoi(argv[i + 1]);   // SVR_OPT_QUEUE_CAPS: tiny queues, passes overflow and are replayed
+    else if (a == "--partition") partition = std::string(argv[i + 1]) == "interleaved" ? 1 : 0;  // bands | interleaved
+    else if (a == "--pick") pick_partition = atoi(argv[i + 1]);     // after N frames of each partition: keep the faster one
     else if (a == "--png") png = argv[i + 1];
     else if (a == "--background") background = atoi(argv[i + 1]);
     else if (a == "--swapchain" && sscanf(argv[i + 1], "%ux%u", &sw, &sh) == 2) {}
@@ -129,10 +136,30 @@ int main(int argc, char** argv) {
       kids.push_back(pid);
     }
     if (rank == 0 && !kids.empty()) {  // rank 0 is the parent itself; it reaps the others at the end (below)
-      static std::vector<pid_t> reap;
-      reap = kids;
+      g_kids = kids;
+      // a rank that fails must not leave the others waiting for it (a test would sit out its timeout): when a child
+      // exits with an error the parent kills the rest and goes; when the parent itself fails, it takes the children along
+      struct sigaction sa {};
+      sa.sa_handler = [](int) {
+        int st = 0;
+        pid_t p;
+        while ((p = waitpid(-1, &st, WNOHANG)) > 0) {
+          for (pid_t& k : g_kids)
+            if (k == p) k = -1;
+          if (!(WIFEXITED(st) && WEXITSTATUS(st) == 0)) {
+            for (pid_t k : g_kids)
+              if (k > 0) kill(k, SIGKILL);
+            _exit(3);
+          }
+        }
+      };
+      sa.sa_flags = SA_RESTART | SA_NOCLDSTOP;
+      sigaction(SIGCHLD, &sa, nullptr);
       atexit([] {
-        for (pid_t p : reap) {
+        signal(SIGCHLD, SIG_DFL);
+        for (pid_t p : g_kids) {
+          if (p <= 0) continue;
+          if (!g_exit_ok) kill(p, SIGKILL);
           int st = 0;
           waitpid(p, &st, 0);
         }
@@ -224,7 +251,8 @@ int main(int argc, char** argv) {
 #define DIST_FN(name) auto name##_ = reinterpret_cast<decltype(&::name)>(dlsym(dh, #name)); if (!name##_) { fprintf(stderr, "missing %s\n", #name); return 1; }
     DIST_FN(svr_dist_get_unique_id) DIST_FN(svr_dist_create) DIST_FN(svr_dist_destroy) DIST_FN(svr_dist_set_bounds) DIST_FN(svr_dist_get_bounds)
     DIST_FN(svr_dist_rebalance) DIST_FN(svr_dist_band) DIST_FN(svr_dist_begin_frame) DIST_FN(svr_dist_end_frame) DIST_FN(svr_dist_wait_frame)
-    DIST_FN(svr_dist_read_frame) DIST_FN(svr_dist_last_error)
+    DIST_FN(svr_dist_read_frame) DIST_FN(svr_dist_last_error) DIST_FN(svr_dist_set_partition) DIST_FN(svr_dist_get_partition) DIST_FN(svr_dist_pick_partition)
+    DIST_FN(svr_dist_replays)
 #undef DIST_FN
     const int tr = transport == "rccl" ? SVR_DIST_RCCL : SVR_DIST_SHM;
     uint8_t id[SVR_DIST_ID_BYTES];
@@ -255,9 +283,38 @@ int main(int argc, char** argv) {
         return 1;
       }
     }
+    if (queue_caps > 0 && eng.api.svr_set_option(eng.ctx, SVR_OPT_QUEUE_CAPS, queue_caps) != SVR_OK) {
+      fprintf(stderr, "rank %d: SVR_OPT_QUEUE_CAPS: %s\n", rank, eng.api.svr_last_error());
+      return 1;
+    }
+    if (svr_dist_set_partition_(dist, partition) != SVR_OK) return 1;
     int in_flight = 0;
     std::vector<uint8_t> image((size_t)w * h * 4);
+    double pick_ms[2] = {0, 0};
     for (int f = 0; f < frames; f++) {
+      if (pick_partition > 0 && f <= 2 * pick_partition && f % pick_partition == 0) {
+        // --pick N: N frames in bands, N interleaved, each timed by this rank; then the collective choice.  The switch
+        // happens between two frames on every rank alike.
+        while (in_flight > 0) {
+          if (svr_dist_wait_frame_(dist, nullptr) != SVR_OK) return 1;
+          in_flight--;
+        }
+        eng.api.svr_sync(eng.ctx);
+        SvrStats st{};
+        eng.api.svr_get_stats(eng.ctx, &st);
+        if (f > 0) pick_ms[f / pick_partition - 1] = st.gpu_time_ms;
+        if (f == 2 * pick_partition) {
+          int picked = -1;
+          if (svr_dist_pick_partition_(dist, (float)pick_ms[0], (float)pick_ms[1], &picked) != SVR_OK) {
+            fprintf(stderr, "rank %d: pick_partition: %s\n", rank, svr_dist_last_error_());
+            return 1;
+          }
+          if (rank == 0) printf("frame %d: bands %.4f ms, interleaved %.4f ms on this rank -> %s\n", f, pick_ms[0], pick_ms[1], picked ? "interleaved" : "bands");
+        } else {
+          if (svr_dist_set_partition_(dist, f / pick_partition) != SVR_OK) return 1;
+          eng.api.svr_set_option(eng.ctx, SVR_OPT_KERNEL_TIMING, 2);  // resets the running means
+        }
+      }
       if (rebalance && f > 0 && f % rebalance == 0) {  // a collective between two frames: every rank, same frame
         eng.api.svr_sync(eng.ctx);
         SvrStats st{};
@@ -280,13 +337,15 @@ int main(int argc, char** argv) {
         in_flight--;
       }
       uint32_t y0 = 0, rows = 0;
-      svr_dist_band_(dist, &y0, &rows);
+      svr_dist_band_(dist, &y0, &rows);  // (interleaved: every rank draws; one without a tile row of its own draws nothing)
       if (svr_dist_begin_frame_(dist) != SVR_OK) {
         fprintf(stderr, "rank %d: begin_frame: %s\n", rank, svr_dist_last_error_());
         return 1;
       }
       eng.update_scene();
-      if (rows && (!eng.draw_background() || !eng.draw_geometry())) {
+      int part_now = 0;
+      svr_dist_get_partition_(dist, &part_now);
+      if ((rows || part_now == SVR_DIST_INTERLEAVED) && (!eng.draw_background() || !eng.draw_geometry())) {
         fprintf(stderr, "rank %d: draw failed: %s\n", rank, eng.error.c_str());
         return 1;
       }
@@ -305,9 +364,15 @@ int main(int argc, char** argv) {
       return 1;
     }
     if (!prefix.empty()) dump(prefix + ".rank" + std::to_string(rank) + ".swapchain", image.data(), image.size());
-    printf("rank %d of %d (%s): %d frames, last one exchanged\n", rank, ranks, transport.c_str(), frames);
+    uint32_t again = 0;
+    svr_dist_replays_(dist, &again);
+    SvrStats st{};
+    eng.api.svr_get_stats(eng.ctx, &st);
+    printf("rank %d of %d (%s): %d frames, last one exchanged; %u passes replayed, %u frames exchanged again\n", rank, ranks,
+           transport.c_str(), frames, st.replayed_passes, again);
     svr_dist_destroy_(dist);
     eng.cleanup();
+    g_exit_ok = true;
     return 0;
   }
   for (int f = 0; f < frames; f++) {

@@ -27,6 +27,7 @@ bool SvrApi::load(const std::string& path, std::string* err) {
   SVR_LOAD(svr_create_sampler) SVR_LOAD(svr_write_material) SVR_LOAD(svr_clear_color) SVR_LOAD(svr_draw_geometry)
   SVR_LOAD(svr_sync) SVR_LOAD(svr_read_color) SVR_LOAD(svr_read_depth) SVR_LOAD(svr_get_stats) SVR_LOAD(svr_last_error)
   SVR_LOAD(svr_backend_name) SVR_LOAD(svr_draw_background) SVR_LOAD(svr_read_swapchain) SVR_LOAD(svr_copy_to_swapchain)
+  SVR_LOAD(svr_set_option)
 #undef SVR_LOAD
   return ok;
 }

@@ -31,7 +31,7 @@ struct SvrApi {
   SVR_FN(svr_create) SVR_FN(svr_destroy) SVR_FN(svr_upload_mesh) SVR_FN(svr_create_image) SVR_FN(svr_create_sampler)
   SVR_FN(svr_write_material) SVR_FN(svr_clear_color) SVR_FN(svr_draw_geometry) SVR_FN(svr_sync) SVR_FN(svr_read_color)
   SVR_FN(svr_read_depth) SVR_FN(svr_get_stats) SVR_FN(svr_last_error) SVR_FN(svr_backend_name)
-  SVR_FN(svr_draw_background) SVR_FN(svr_read_swapchain) SVR_FN(svr_copy_to_swapchain)
+  SVR_FN(svr_draw_background) SVR_FN(svr_read_swapchain) SVR_FN(svr_copy_to_swapchain) SVR_FN(svr_set_option)
 #undef SVR_FN
   bool load(const std::string& path, std::string* err);
   void unload();

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, width, height, out_dir, present, bounds=None, rebalance=False):
+def _worker(rank, world, port, width, height, out_dir, present, bounds=None, rebalance=False, partition="bands"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -38,6 +38,12 @@ def _worker(rank, world, port, width, height, out_dir, present, bounds=None, reb
         plan = D.BandPlan(height, world, balanced=rebalance, min_gain=0.0)
         if bounds is not None:
             plan.bounds = list(bounds)
+        if partition == "pick":  # the collective choice: this rank found bands cheaper, rank 1 found them dearer — the slowest rank decides
+            assert plan.pick(torch, dist, torch.device("cpu"), 1.0 if rank == 0 else 5.0, 3.0) == "interleaved"
+            assert plan.pick(torch, dist, torch.device("cpu"), 1.0, 3.0 if rank == 0 else 0.5) == "bands"
+            assert plan.pick(torch, dist, torch.device("cpu"), 4.0, 3.0 if rank == 0 else 0.5) == "interleaved"
+        else:
+            plan.partition = partition
         slots = [D.ShardedFrame(torch, r, rank, world, torch.device("cpu"), pkg.abi.COLOR_RGBA16F, bind=False, present=present, plan=plan)
                  for _ in range(2)]
         for f in range(3):  # three frames through two slots, asynchronous gathers
@@ -91,6 +97,23 @@ def test_unequal_bands_travel_point_to_point(tmp_path, oracle, world, bounds):
         assert np.array_equal(np.load(tmp_path / f"rank{rank}.npy"), ref), f"rank {rank} with bounds {bounds}"
 
 
+@pytest.mark.parametrize("world,size,present,partition", [(2, (96, 54), True, "interleaved"), (3, (80, 100), True, "interleaved"),
+                                                          (4, (64, 70), True, "interleaved"), (2, (80, 100), False, "interleaved"),
+                                                          (2, (96, 135), True, "pick")])
+def test_interleaved_tile_rows_travel_as_grouped_allgathers(tmp_path, oracle, world, size, present, partition):
+    """rank r renders the tile rows t with t % world == r; every group of `world` tile rows is one in-place all-gather.
+    54 rows = two tile rows for two ranks; 100 rows = four for three (the last 4 rows tall); 70 rows = three for four (a
+    rank with nothing); the RGBA16F target instead of the swapchain image; BandPlan.pick's collective choice."""
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    w, h = size
+    mp.spawn(_worker, args=(world, _free_port(), w, h, str(tmp_path), present, None, False, partition), nprocs=world, join=True)
+    full = T.render_sponza(oracle, w, h, lod=8, tex_size=32)
+    ref = full["rgba8"][..., [2, 1, 0, 3]] if present else full["color"]
+    for rank in range(world):
+        assert np.array_equal(np.load(tmp_path / f"rank{rank}.npy"), ref), f"rank {rank} of {world}, {partition}"
+
+
 def test_rebalance_is_a_collective_that_keeps_the_frame(tmp_path, oracle):
     """Skewed bands to begin with, re-cut between frames from the ranks' reported row costs (all_reduce of the profile)."""
     torch = pytest.importorskip("torch")
@@ -137,6 +160,14 @@ def test_balanced_bounds_minimise_the_heaviest_band():
 
 def test_band_rows_partition():
     D = pkg.dist
+    for h in (1, 31, 32, 33, 90, 2160, 4320):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                seen += [y for y0, n in D.interleaved_rows(h, r, world) for y in range(y0, y0 + n)]
+            assert sorted(seen) == list(range(h))
+            hp = D.padded_height(h, world)
+            assert hp >= h and hp % world == 0 and hp >= -(-((h + 31) // 32) // world) * world * 32
     for h in (1, 7, 54, 55, 2160, 4320, 1080):
         for world in (1, 2, 3, 4, 8):
             rows = [D.band_rows(h, r, world) for r in range(world)]

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, width, height, out_dir):
+def _worker(rank, world, port, width, height, out_dir, partition="bands", queue_caps=None):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -37,7 +37,11 @@ def _worker(rank, world, port, width, height, out_dir):
         dev = torch.device("cuda", 0)
         r, scene, opaque, transparent = T.setup_sponza(hip, width, height, lod=8, tex_size=32)
         r.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        slots = [P.dist.ShardedFrame(torch, r, rank, world, dev, P.abi.COLOR_RGBA16F) for _ in range(2)]
+        plan = P.dist.BandPlan(height, world, balanced=False)
+        plan.partition = partition
+        if queue_caps is not None:
+            r.set_option(P.abi.OPT_QUEUE_CAPS, queue_caps)  # the first passes overflow, are void, and replayed later
+        slots = [P.dist.ShardedFrame(torch, r, rank, world, dev, P.abi.COLOR_RGBA16F, plan=plan) for _ in range(2)]
         for f in range(5):  # five frames through two slots, nothing fenced in between
             s = slots[f % 2]
             s.begin()
@@ -50,6 +54,7 @@ def _worker(rank, world, port, width, height, out_dir):
         r.sync()
         torch.cuda.synchronize(dev)
         np.save(os.path.join(out_dir, f"rank{rank}.npy"), slots[0].image().cpu().numpy())
+        np.save(os.path.join(out_dir, f"again{rank}.npy"), np.array([sum(s.exchanged_again for s in slots), r.get_stats().replayed_passes]))
         r.close()
         dist.barrier()
     finally:
@@ -71,3 +76,41 @@ def test_two_ranks_present_and_gather(tmp_path, hip, size):
         got = np.load(tmp_path / f"rank{rank}.npy")
         assert got.shape == ref.shape
         assert np.array_equal(got, ref), f"rank {rank}: gathered swapchain image differs from the single-process frame"
+
+
+def _reference(hip, w, h):
+    r, scene, opaque, transparent = T.setup_sponza(hip, w, h, lod=8, tex_size=32)
+    r.clear_color((1, 1, 1, 1))
+    r.draw_geometry(scene, opaque, transparent)
+    ref = r.read_swapchain(w, h, pkg.abi.SWAPCHAIN_B8G8R8A8)
+    r.close()
+    return ref
+
+
+@pytest.mark.parametrize("world,size", [(2, (192, 108)), (3, (160, 91))])
+def test_interleaved_tile_rows_present_and_gather(tmp_path, hip, world, size):
+    """rank r renders tile rows t % world == r into its rows of the full frame, presents them in place, and every group
+    of `world` tile rows is gathered in place (108 rows: four tile rows, the last 12 rows tall; 91 rows: three for three)"""
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    w, h = size
+    mp.spawn(_worker, args=(world, _free_port(), w, h, str(tmp_path), "interleaved"), nprocs=world, join=True)
+    ref = _reference(hip, w, h)
+    for rank in range(world):
+        assert np.array_equal(np.load(tmp_path / f"rank{rank}.npy"), ref), f"rank {rank} of {world}"
+
+
+@pytest.mark.parametrize("partition", ["bands", "interleaved"])
+def test_a_replayed_pass_is_exchanged_again(tmp_path, hip, partition):
+    """queues start tiny: the first passes overflow, their presents are void and say so in the status words that travel
+    behind the rows; every rank then fences and exchanges the slot again before it reuses it (dist.py _repair)"""
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    w, h = 192, 108
+    mp.spawn(_worker, args=(2, _free_port(), w, h, str(tmp_path), partition, 16), nprocs=2, join=True)
+    ref = _reference(hip, w, h)
+    again = [np.load(tmp_path / f"again{rank}.npy") for rank in range(2)]
+    for rank in range(2):
+        assert np.array_equal(np.load(tmp_path / f"rank{rank}.npy"), ref), f"rank {rank}"
+    assert again[0][0] == again[1][0] >= 1, again          # the repair is collective
+    assert max(a[1] for a in again) >= 1, again            # and there was something to repair

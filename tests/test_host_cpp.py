@@ -159,3 +159,42 @@ def test_cpp_sharded_frame(tmp_path, hip):
             assert "re-cut" in log, log
     log, images = run_dist_demo(hip.path, str(tmp_path / "rccl1"), 1, "rccl")
     assert np.array_equal(images[0], want), log
+
+
+@pytest.mark.gpu
+def test_cpp_sharded_frame_interleaved(tmp_path, hip):
+    """the interleaved partition (tile row t on rank t % world): the rows travel as grouped in-place all-gathers, here
+    through the shared-memory transport; 90 rows = three tile rows, so with three ranks each owns one, with two one owns
+    two, with four one owns nothing; also the collective choice between the two partitions from measured times"""
+    single = str(tmp_path / "single")
+    run_demo(hip.path, single)
+    want = np.fromfile(single + ".swapchain", dtype=np.uint8).reshape(H, W, 4)
+    for ranks in (2, 3, 4):
+        log, images = run_dist_demo(hip.path, str(tmp_path / f"i{ranks}"), ranks, "shm", ("--partition", "interleaved"))
+        for r, img in enumerate(images):
+            assert np.array_equal(img, want), f"{ranks} ranks interleaved: rank {r}\n{log}"
+    log, images = run_dist_demo(hip.path, str(tmp_path / "pick"), 2, "shm", ("--pick", "2", "--frames", "7"))
+    assert "-> bands" in log or "-> interleaved" in log, log
+    for r, img in enumerate(images):
+        assert np.array_equal(img, want), f"after the pick: rank {r}\n{log}"
+    log, images = run_dist_demo(hip.path, str(tmp_path / "rccl1i"), 1, "rccl", ("--partition", "interleaved"))
+    assert np.array_equal(images[0], want), log
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("partition", ["bands", "interleaved"])
+def test_cpp_sharded_frame_survives_an_overflow(tmp_path, hip, partition):
+    """SVR_OPT_QUEUE_CAPS tiny: the first passes overflow their queues, are void and replayed behind the exchange — the
+    status word that travels with the rows makes every rank exchange the frame again (include/svr_dist.h): the image a
+    rank hands out is still the single-process one, and the log says that the repair ran"""
+    import re
+    single = str(tmp_path / "single")
+    run_demo(hip.path, single)
+    want = np.fromfile(single + ".swapchain", dtype=np.uint8).reshape(H, W, 4)
+    log, images = run_dist_demo(hip.path, str(tmp_path / f"q{partition}"), 2, "shm", ("--queue-caps", "8", "--partition", partition))
+    for r, img in enumerate(images):
+        assert np.array_equal(img, want), f"rank {r}\n{log}"
+    replayed = [int(m) for m in re.findall(r"(\d+) passes replayed", log)]
+    again = [int(m) for m in re.findall(r"(\d+) frames exchanged again", log)]
+    assert len(replayed) == 2 and max(replayed) >= 1, log
+    assert len(again) == 2 and min(again) >= 1 and again[0] == again[1], log  # the repair is collective
