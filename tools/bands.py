@@ -3,8 +3,9 @@
 Rank r of N renders the rows [r*H/N, (r+1)*H/N) (dist.py); this times every band of N = 1, 2, 4, 8 in
 turn on the one GPU present (scissor = the band, present of the band included, no gather) and prints
 the slowest band per N: the frame rate an N-GPU run cannot exceed however fast the gather is.
+--interleaved does the same for the other partition (rank r = the tile rows t with t % N == r).
 
-    python tools/bands.py [--frames 200]
+    python tools/bands.py [--frames 200] [--balanced | --interleaved] [--stages]
 """
 import argparse
 import os
@@ -29,6 +30,8 @@ def main():
     ap.add_argument("--wall", action="store_true", help="--balanced: scale by the band's wall-clock frame time instead of its GPU time")
     ap.add_argument("--gpu", action="store_true", help="--balanced: scale by the band's whole GPU time instead of its tile stage's (geometry + binning are the same for every band: spread over its rows they make a short, dense band look dearer per row than it is, and the cut swings)")
     ap.add_argument("--stages", action="store_true", help="also print per-stage kernel times (adds events to the stream)")
+    ap.add_argument("--interleaved", action="store_true", help="the other partition of SURVEY 8e: rank r renders the tile rows t with t %% N == r (svr_set_row_interleave)")
+    ap.add_argument("--ns", default="1,2,4,8")
     args = ap.parse_args()
     import torch
     pkg = g.load_package()
@@ -50,7 +53,12 @@ def main():
         r.copy_to_swapchain(swap.data_ptr(), W, H, A.SWAPCHAIN_B8G8R8A8)
 
     def time_band(y0, rows, n, rk):
-        r.set_scissor(0, y0, W, rows)
+        if args.interleaved:
+            r.set_scissor(0, 0, W, H)
+            r.set_row_interleave(n, rk)
+        else:
+            r.set_row_interleave(1, 0)
+            r.set_scissor(0, y0, W, rows)
         r.set_option(A.OPT_KERNEL_TIMING, 0)
         for _ in range(10):
             frame(y0, rows)
@@ -72,11 +80,14 @@ def main():
             tile_ms = st.tile_ms
             stage = f" (geometry {st.geometry_ms:.3f} binning {st.binning_ms:.3f} tile {st.tile_ms:.3f})"
         costs, y0c, rowsc = r.row_costs()
-        print(f"  N={n} band {rk}: rows {y0}..{y0 + rows}: {ms:.4f} ms/frame (host enqueue {host_ms:.4f}){stage}", flush=True)
+        what = f"tile rows {rk} mod {n}" if args.interleaved else f"rows {y0}..{y0 + rows}"
+        print(f"  N={n} band {rk}: {what}: {ms:.4f} ms/frame (host enqueue {host_ms:.4f}){stage}", flush=True)
+        if args.interleaved:
+            return ms, (gpu_ms if args.gpu else tile_ms), np.zeros(H, dtype=np.int64)
         return ms, (gpu_ms if args.gpu else tile_ms), pkg.dist.BandPlan.spread(costs, y0c, rowsc, H)
 
     base = None
-    for n in (1, 2, 4, 8):
+    for n in [int(v) for v in args.ns.split(",")]:
         band = (H + n - 1) // n
         plan = pkg.dist.BandPlan(H, n, balanced=args.balanced, min_gain=0.0)
         for it in range(args.iterations if args.balanced and n > 1 else 1):
@@ -94,7 +105,7 @@ def main():
             worst, mean = max(per), float(np.mean(per))
             if base is None:
                 base = worst
-            print(f"N={n}{' iteration ' + str(it) + ' rows ' + str(bounds) if args.balanced else ''}: slowest band {worst:.4f} ms, "
+            print(f"N={n}{' interleaved' if args.interleaved else ''}{' iteration ' + str(it) + ' rows ' + str(bounds) if args.balanced else ''}: slowest band {worst:.4f} ms, "
                   f"mean {mean:.4f} ms (slowest / mean {worst / mean:.3f}) -> at most {base / worst:.2f}x of N=1 "
                   f"({base / worst / n * 100:.0f} % efficiency before the gather)", flush=True)
             if args.balanced:
