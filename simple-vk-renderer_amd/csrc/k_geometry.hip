@@ -5,12 +5,12 @@
 // transform (src/vk_engine.cpp:1421-1429) and the rasteriser's triangle setup.
 //
 // One lane per triangle, one wave per 64 consecutive triangles of ONE draw (WaveChunk), so the
-// draw's matrices are wave-uniform.  The vertex shader is re-run per triangle corner instead of
-// being cached in an intermediate post-transform buffer: a 48-byte vertex gather out of L2 plus
-// ~30 fma is cheaper on this chip than a second pass that writes and re-gathers transformed
-// vertices (DESIGN.md "Geometry").  Triangles that need real clipping (any vertex beyond the
-// near/far planes or the guard band) are queued and handled by clip_kernel so this kernel keeps
-// no polygon arrays in scratch.
+// draw's matrices are wave-uniform.  A chunk's vertices are read as they lie — the index-group table names
+// the run of the vertex buffer its 192 indices touch, consecutive lanes read consecutive 48-byte vertices —
+// run through mesh.vert ONCE each and parked in LDS for the chunk's triangles to pick up (runs longer than 128
+// vertices fall back to a gather per corner); no post-transform buffer goes through memory.  Triangles that
+// need real clipping (any vertex beyond the near/far planes or the guard band) are queued and handled by
+// clip_kernel so this kernel keeps no polygon arrays in scratch.
 #include <algorithm>
 
 #include "svr_bin.h"

@@ -1345,8 +1345,12 @@ void launch_tiles(const FrameParams& P, int color_format, bool count_fragments, 
   dim3 grid(split ? P.n_tiles + SPLIT_EXTRA : P.n_tiles), block(256);
   const bool report = count_fragments || P.flatten;
   hipEvent_t tile_done = report ? nullptr : done;
-  // SVR_TILE_LDS_PAD (development): extra dynamic LDS per workgroup, i.e. fewer workgroups per CU without a rebuild
+#ifdef SVR_DEBUG_LDS_PAD  // development builds only (tools/build_variant.sh): extra dynamic LDS per workgroup from the
+  // environment, i.e. fewer workgroups per CU without a rebuild; the product reads no environment variable
   static const uint32_t lds_pad = [] { const char* e = getenv("SVR_TILE_LDS_PAD"); return e ? (uint32_t)atoi(e) : 0u; }();
+#else
+  constexpr uint32_t lds_pad = 0u;
+#endif
 #define SVR_LAUNCH_TILES(FMT, INSTR, SPLIT) hipExtLaunchKernelGGL((tile_kernel<FMT, INSTR, SPLIT>), grid, block, lds_pad, s, start, tile_done, 0, P)
   if (color_format == SVR_COLOR_RGBA16F) {
     if (count_fragments) {

@@ -16,6 +16,6 @@ for set in "TA_TA_BUSY GRBM_GUI_ACTIVE" "TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_ST
   echo "pass $i: $set" >> $root/gpurun_out/pmc_mem_$tag.progress
   timeout -k 10 150 rocprofv3 --kernel-trace --pmc $set -d $out/s$i -o s$i -- python3 $root/tools/frames.py --frames 6 --timing 0 "$@" > $out/s$i.log 2>&1 || echo "set $i failed" >> $root/gpurun_out/pmc_mem_$tag.progress
 done
-python3 $root/tools/pmc_summary.py $(find $out -name "*_results.db" | sort) > $root/gpurun_out/pmc_mem_$tag.txt 2>&1
+{ python3 $root/tools/pmc_summary.py $(find $out -name "*_results.db" | sort); grep failed $root/gpurun_out/pmc_mem_$tag.progress | sed 's/^/# FAILED /'; } > $root/gpurun_out/pmc_mem_$tag.txt 2>&1
 grep -E "^#|tile_kernel<0, false, false>" $root/gpurun_out/pmc_mem_$tag.txt
 rm -rf $out
