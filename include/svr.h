@@ -286,7 +286,9 @@ int svr_run_vertex_shader(SvrContext* ctx, int shader, SvrMesh mesh, uint32_t fi
  * process; results are identical either way).  bit0: tile kernel walks tiles row-major instead of
  * heaviest-first.  bit1: geometry + binning run on the caller's stream instead of overlapping the
  * previous pass's tile stage on an internal stream.  bit2: svr_clear_color runs at once instead of riding in
- * the next pass.  bit3: heavy tiles are rendered by one workgroup instead of four row quarters.
+ * the next pass.  bit3: heavy tiles are rendered by one workgroup instead of four row quarters.  bit4: finished passes are
+ * looked at by fences only (svr_sync, read-backs, svr_get_stats), not in passing by other calls: a queue overflow
+ * (SVR_OPT_QUEUE_CAPS) is then always found late — what the tests of the replay behind an exchange need.
  * SVR_OPT_DEVICE_FLATTEN: where svr_draw_geometry's host half runs — is_visible, the sort and the
  * per-object draw records (src/vk_engine.cpp:1361-1378, 1412-1457).  0 (default): on the device from
  * 2048 objects up, on the host below; 1: always on the device; 2: always on the host.  Same frames

@@ -184,6 +184,10 @@ __global__ __launch_bounds__(256, 4) void setup_kernel(FrameParams P) {
     const unsigned long long act = __ballot(tri < d.tri_count), okm = __ballot(ok);
     uint4* wave_recs = reinterpret_cast<uint4*>(P.recs + (d.tri_base + ch.first_tri));
     uint4* sl = s_tr[threadIdx.x >> 6];
+    // s_tr is also where the chunk's shaded vertices were parked (as VOut): every lane's reads of them lie in front of
+    // this line, and nothing but this barrier keeps the compiler from moving the stores below across them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int half = 0; half < 2; half++) {
 #pragma unroll

@@ -1035,41 +1035,49 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
   // ---- phase A: opaque visibility
   if (n_op) {
     for (uint32_t i = threadIdx.x; i < TILE * TILE; i += 256u) s_depth[i] = 0ull;  // ordered by scan_columns' first barrier
-    if (QUARTER && n_op > 2u * BATCH && n_op <= QUARTER_LIST_CAP) {
+    if (QUARTER && n_op > 2u * BATCH) {
       // A quarter of an opaque-heavy tile: most of the bin's triangles do not reach its 8 rows, and staging
       // them costs as much as in the whole tile.  One pass over the record headers (indices, then bounding
       // rows: two round trips per 1024 entries) leaves the quarter's own list in LDS, behind the depth tile.
+      // The bin is taken in windows of QUARTER_LIST_CAP entries (what the list holds if all of a window stay):
+      // visibility is a maximum, so it may be found window by window.  (Bins beyond the capacity used to be
+      // walked whole by each of the four quarters: configs[4]'s deepest tiles hold 12 000 triangles, and a
+      // rank of eight was as slow as those tiles' quarters — 0.44 ms for an eighth of a 1.5-ms tile stage.)
       uint32_t* s_list = reinterpret_cast<uint32_t*>(s_c + LDS_Z_OFF);
-      if (threadIdx.x == 0) s_idx[0] = 0u;
-      __syncthreads();
-      for (uint32_t base = 0; base < n_op; base += 1024u) {
-        uint32_t ri[4];
-        uint2 box[4];
+      for (uint32_t win = 0; win < n_op; win += QUARTER_LIST_CAP) {
+        const uint32_t n_win = min(n_op - win, QUARTER_LIST_CAP);
+        __syncthreads();  // the previous window's list is consumed, its count read by everybody
+        if (threadIdx.x == 0) s_idx[0] = 0u;
+        __syncthreads();
+        for (uint32_t base = 0; base < n_win; base += 1024u) {
+          uint32_t ri[4];
+          uint2 box[4];
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-          uint32_t i = base + 256u * k + threadIdx.x;
-          ri[k] = i < n_op ? P.bins[off_op + i] : 0u;
-        }
+          for (uint32_t k = 0; k < 4; k++) {
+            uint32_t i = base + 256u * k + threadIdx.x;
+            ri[k] = i < n_win ? P.bins[off_op + win + i] : 0u;
+          }
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-          uint32_t i = base + 256u * k + threadIdx.x;
-          box[k] = i < n_op ? *reinterpret_cast<const uint2*>(P.recs + ri[k]) : make_uint2(0u, 0u);
-        }
+          for (uint32_t k = 0; k < 4; k++) {
+            uint32_t i = base + 256u * k + threadIdx.x;
+            box[k] = i < n_win ? *reinterpret_cast<const uint2*>(P.recs + ri[k]) : make_uint2(0u, 0u);
+          }
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-          uint32_t i = base + 256u * k + threadIdx.x;
-          int miny = (int)(int16_t)(box[k].x >> 16), maxy = (int)(int16_t)(box[k].y >> 16);
-          bool keep = i < n_op && maxy >= sub_y0 && miny <= sub_y0 + nrows - 1;
-          unsigned long long m = __ballot(keep);
-          uint32_t at = 0;
-          if (lane == 0 && m) at = atomicAdd(&s_idx[0], (uint32_t)__popcll(m));  // LDS
-          at = __shfl(at, 0);
-          if (keep) s_list[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ri[k];
+          for (uint32_t k = 0; k < 4; k++) {
+            uint32_t i = base + 256u * k + threadIdx.x;
+            int miny = (int)(int16_t)(box[k].x >> 16), maxy = (int)(int16_t)(box[k].y >> 16);
+            bool keep = i < n_win && maxy >= sub_y0 && miny <= sub_y0 + nrows - 1;
+            unsigned long long m = __ballot(keep);
+            uint32_t at = 0;
+            if (lane == 0 && m) at = atomicAdd(&s_idx[0], (uint32_t)__popcll(m));  // LDS
+            at = __shfl(at, 0);
+            if (keep) s_list[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ri[k];
+          }
         }
+        __syncthreads();
+        const uint32_t n_mine = s_idx[0];
+        scan_columns<INSTR, true>(P, s_cov, s_list, 0u, n_mine, s_depth, tx0, ty0, sub_y0, nrows, n_raster);
       }
-      __syncthreads();
-      const uint32_t n_mine = s_idx[0];
-      scan_columns<INSTR, true>(P, s_cov, s_list, 0u, n_mine, s_depth, tx0, ty0, sub_y0, nrows, n_raster);
     } else {
       scan_columns<INSTR, false>(P, s_cov, nullptr, off_op, n_op, s_depth, tx0, ty0, QUARTER ? sub_y0 : ty0, nrows, n_raster);
     }

@@ -740,7 +740,7 @@ int finish_pending(SvrContext* ctx) {  // the fence
   if (int e = flush_clear(ctx)) return e;
   return retire_ops(ctx, true);
 }
-int poll_pending(SvrContext* ctx) { return retire_ops(ctx, false); }
+int poll_pending(SvrContext* ctx) { return (ctx->tuning & TUNE_NO_POLL) ? SVR_OK : retire_ops(ctx, false); }
 
 // the scissor's 32-row tile rows this context renders (svr_set_row_interleave: index % rstride == roff)
 uint32_t owned_tile_rows(const SvrContext* ctx) {

@@ -31,6 +31,7 @@ constexpr uint32_t TUNE_NO_TILE_ORDER = 1u;   // tile kernel walks tiles row-maj
 constexpr uint32_t TUNE_NO_LAZY_CLEAR = 4u;   // svr_clear_color runs its own kernel at once instead of riding in the next pass
 constexpr uint32_t TUNE_NO_PIPELINE = 2u;     // geometry+binning on the caller's stream too (no overlap between passes)
 constexpr uint32_t TUNE_NO_SPLIT = 8u;        // heavy tiles are not cut into four row quarters
+constexpr uint32_t TUNE_NO_POLL = 16u;        // finished passes are validated at fences only (tests: an overflow is always found late)
 
 // A heavy tile is rendered by FOUR workgroups, one per 8 rows (tile kernel "quarters").  The slowest tile
 // bounds the tile kernel however many CUs are idle, and ordered blending makes a tile with a deep transparent

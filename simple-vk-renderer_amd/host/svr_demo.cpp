@@ -283,7 +283,10 @@ int main(int argc, char** argv) {
         return 1;
       }
     }
-    if (queue_caps > 0 && eng.api.svr_set_option(eng.ctx, SVR_OPT_QUEUE_CAPS, queue_caps) != SVR_OK) {
+    // (SVR_OPT_TUNING bit 4 with it: the overflow is found at a fence, not in passing, so the present behind the
+    // void pass is void too and the exchange carries stale rows — the case svr_dist_wait_frame repairs)
+    if (queue_caps > 0 && (eng.api.svr_set_option(eng.ctx, SVR_OPT_QUEUE_CAPS, queue_caps) != SVR_OK ||
+                           eng.api.svr_set_option(eng.ctx, SVR_OPT_TUNING, 16) != SVR_OK)) {
       fprintf(stderr, "rank %d: SVR_OPT_QUEUE_CAPS: %s\n", rank, eng.api.svr_last_error());
       return 1;
     }

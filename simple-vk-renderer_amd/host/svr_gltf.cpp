@@ -138,7 +138,9 @@ struct AccessorReader {
     ctype = acc["componentType"].int_or(0);
     csize = component_size(ctype);
     ncomp = type_components(acc["type"].string_or(""));
-    count = (size_t)acc["count"].int_or(0);
+    const long long count_ll = acc["count"].int_or(0);
+    if (count_ll < 0 || count_ll > (1ll << 31)) return fail(err, "accessor count out of range");  // (a hostile file: negative -> huge)
+    count = (size_t)count_ll;
     normalized = acc["normalized"].kind == Value::Bool && acc["normalized"].b;
     if (!csize || !ncomp) return fail(err, "unsupported accessor type");
     const size_t elem = (size_t)(csize * ncomp);
@@ -146,18 +148,29 @@ struct AccessorReader {
     if (!acc.has("bufferView") && !sparse) return fail(err, "accessor without a bufferView");
     if (acc.has("bufferView")) {
       if (!buffer_view(a, acc["bufferView"].int_or(-1), view)) return fail(err, "bad bufferView");
-      offset = (size_t)acc["byteOffset"].int_or(0);
+      const long long off_ll = acc["byteOffset"].int_or(0);
+      if (off_ll < 0) return fail(err, "negative accessor byteOffset");
+      offset = (size_t)off_ll;
       stride = view.stride ? view.stride : elem;
-      if (count && offset + (count - 1) * stride + elem > view.length) return fail(err, "accessor runs past its bufferView");
+      // by division: offset + (count - 1) * stride + elem must not wrap on its way past the length check
+      if (count && (offset > view.length || elem > view.length - offset || (count - 1) > (view.length - offset - elem) / stride))
+        return fail(err, "accessor runs past its bufferView");
     }
     if (!sparse) return true;
     // Sparse accessor (glTF 2.0 section 3.6.2.3; fastgltf's iterateAccessor, src/vk_loader.cpp:311-357, reads them):
     // the base elements — zeros without a bufferView — with `count` of them replaced; made dense here once.
-    dense.assign(count * elem, 0);
+    if (count > (size_t(1) << 28) / elem) return fail(err, "sparse accessor too large");  // 256 MiB of elements at most
+    try {
+      dense.assign(count * elem, 0);
+    } catch (const std::exception&) {
+      return fail(err, "out of memory for a sparse accessor");
+    }
     if (acc.has("bufferView"))
       for (size_t i = 0; i < count; i++) std::memcpy(dense.data() + i * elem, view.data + offset + i * stride, elem);
     const Value& sp = acc["sparse"];
-    const size_t n = (size_t)sp["count"].int_or(0);
+    const long long n_ll = sp["count"].int_or(0), ioff_ll = sp["indices"]["byteOffset"].int_or(0), voff_ll = sp["values"]["byteOffset"].int_or(0);
+    if (n_ll < 0 || (size_t)n_ll > count || ioff_ll < 0 || voff_ll < 0) return fail(err, "sparse count / offsets out of range");
+    const size_t n = (size_t)n_ll;
     const Value& si = sp["indices"];
     const Value& sv = sp["values"];
     View iv, vv;
@@ -165,7 +178,8 @@ struct AccessorReader {
     const long long ict = si["componentType"].int_or(0);
     const size_t isz = (size_t)component_size(ict), ioff = (size_t)si["byteOffset"].int_or(0), voff = (size_t)sv["byteOffset"].int_or(0);
     if (ict != 5121 && ict != 5123 && ict != 5125) return fail(err, "bad sparse index type");
-    if (ioff + n * isz > iv.length || voff + n * elem > vv.length) return fail(err, "sparse data runs past its bufferView");
+    if (ioff > iv.length || n > (iv.length - ioff) / isz || voff > vv.length || n > (vv.length - voff) / elem)
+      return fail(err, "sparse data runs past its bufferView");
     for (size_t k = 0; k < n; k++) {
       uint32_t idx = 0;
       std::memcpy(&idx, iv.data + ioff + k * isz, isz);  // little-endian u8 / u16 / u32

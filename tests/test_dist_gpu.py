@@ -41,6 +41,7 @@ def _worker(rank, world, port, width, height, out_dir, partition="bands", queue_
         plan.partition = partition
         if queue_caps is not None:
             r.set_option(P.abi.OPT_QUEUE_CAPS, queue_caps)  # the first passes overflow, are void, and replayed later
+            r.set_option(P.abi.OPT_TUNING, 16)              # ... found at a fence, not in passing: the present behind them is void
         slots = [P.dist.ShardedFrame(torch, r, rank, world, dev, P.abi.COLOR_RGBA16F, plan=plan) for _ in range(2)]
         for f in range(5):  # five frames through two slots, nothing fenced in between
             s = slots[f % 2]
