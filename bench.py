@@ -180,7 +180,9 @@ def main():
     present = world > 1 and not args.gather_fp16
     # cost-balanced row bands (dist.BandPlan): re-cut from the ranks' tile-row costs every --rebalance frames
     plan = D.BandPlan(H, world, balanced=not args.equal_bands, min_gain=args.min_gain)
-    slots = [D.ShardedFrame(torch, r, rank, world, dev, A.COLOR_RGBA16F, present=present, plan=plan) for _ in range(2)]
+    # verify="fence": frames are only handed out at fences here, and a second collective per frame would cost the host
+    # 20-30 us against 60-us frames (dist.py ShardedFrame; libsvr_dist.so verifies every frame)
+    slots = [D.ShardedFrame(torch, r, rank, world, dev, A.COLOR_RGBA16F, present=present, plan=plan, verify="fence") for _ in range(2)]
     handles = sc.upload(r)
     inst = S.config5_instances() if args.instances == 16 else None
     opaque, transparent = sc.render_objects(handles, instance_transforms=inst)

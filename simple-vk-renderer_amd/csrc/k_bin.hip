@@ -9,14 +9,15 @@
 //
 // The setup kernel itself (k_geometry.hip, svr_bin.h emit_small_pairs) decides the tiles of every
 // triangle of <= 16 tiles while its bbox and edge functions are in registers, and appends (bin, record)
-// pairs to one list.  count_kernel takes a slot in its bin for every pair (and walks what setup could
-// not take — the clipper's records and the queued big triangles — wave per record, appending their
-// pairs with the slot already taken); offsets_kernel gives every bin a span; fill scatters.
+// pairs to one list.  count_kernel takes a slot in its bin for every pair; the same launch runs the clipper and
+// walks what setup could not take — the clipper's pieces and the queued big triangles — wave per record,
+// appending their pairs with the slot already taken; offsets_kernel gives every bin a span; fill scatters.
 #include <hip/hip_ext.h>
 
 #include <algorithm>
 
 #include "svr_bin.h"
+#include "svr_clip.h"
 #include "svr_launch.h"
 
 namespace svr {
@@ -47,69 +48,176 @@ __device__ __forceinline__ RecBox load_box(const TriRec* rec) {
   return b;
 }
 
-// The "rest": records the lane-per-triangle path of the setup kernel does not take — the clipper's
-// pieces and the queued triangles over 16 tiles.  One WAVE per record (all loads wave-uniform: one
-// broadcast each), lanes take the tiles of its bbox 64 at a time; each hit takes its slot from the
-// tile counter and is appended to the pair list with the slot already known.
-__device__ __forceinline__ void bin_rest(const FrameParams& P, uint32_t first_wave, uint32_t n_waves) {
+// One record, wave-wide: the lanes take the tiles of its bbox 64 at a time (all loads wave-uniform: one broadcast
+// each); each hit takes its slot from the tile counter and is appended to the pair list with the slot already known.
+// These pairs grow from the END of the list downwards (n_pairs_rest) while the setup kernel's lie at its head
+// (n_pairs, final when this launch starts): the two parts never need a snapshot of each other's length.
+__device__ __forceinline__ void bin_one(const FrameParams& P, uint32_t r, int minx, int miny, int maxx, int maxy, uint32_t binbase,
+                                        const EdgeSet& e, uint32_t n_setup) {
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long below = (1ull << lane) - 1ull;
-  uint32_t n_extra = min(P.counters->n_extra, P.extra_cap), n_big = min(P.counters->n_big, P.n_tris);
-  uint32_t n_items = n_extra + n_big;
-  for (uint32_t it = first_wave; it < n_items; it += n_waves) {
-    uint32_t r = it < n_extra ? P.n_tris + it : P.big_queue[it - n_extra];
-    const TriRec* rec = P.recs + r;
-    RecBox b = load_box(rec);
-    if (!b.valid) continue;  // wave-uniform
-    TileRange tr = tile_range(P, b.minx, b.miny, b.maxx, b.maxy, true);
-    uint32_t binbase = (b.flags & F_TRANSPARENT) ? P.n_tiles : 0u;
-    EdgeSet e = load_edges(rec);
-    for (int t0 = 0; t0 < tr.nt; t0 += 64) {
-      int t = t0 + (int)lane;
-      bool hit = t < tr.nt;
-      uint32_t bin = 0;
-      if (hit) {
-        int ty = tr.ty0 + t / tr.ntx, tx = tr.tx0 + t % tr.ntx;
-        if (tr.nt > 4) {
-          int x0 = max(b.minx, (int)P.sx + tx * TILE), x1 = min(b.maxx, (int)P.sx + tx * TILE + TILE - 1);
-          int y0 = max(b.miny, tile_row_y(P, ty)), y1 = min(b.maxy, tile_row_y(P, ty) + TILE - 1);
-          hit = box_overlaps(e, x0, y0, x1, y1);
-        }
-        bin = binbase + (uint32_t)ty * P.tiles_x + (uint32_t)tx;
+  TileRange tr = tile_range(P, minx, miny, maxx, maxy, true);
+  for (int t0 = 0; t0 < tr.nt; t0 += 64) {
+    int t = t0 + (int)lane;
+    bool hit = t < tr.nt;
+    uint32_t bin = 0;
+    if (hit) {
+      int ty = tr.ty0 + t / tr.ntx, tx = tr.tx0 + t % tr.ntx;
+      if (tr.nt > 4) {
+        int x0 = max(minx, (int)P.sx + tx * TILE), x1 = min(maxx, (int)P.sx + tx * TILE + TILE - 1);
+        int y0 = max(miny, tile_row_y(P, ty)), y1 = min(maxy, tile_row_y(P, ty) + TILE - 1);
+        hit = box_overlaps(e, x0, y0, x1, y1);
       }
-      unsigned long long hits = __ballot(hit);
-      if (!hits) continue;
-      uint32_t slot = 0, base = 0;
-      if (hit) slot = atomicAdd(&P.tile_count[bin], 1u);
-      if (lane == 0) base = atomicAdd(&P.counters->n_pairs, (uint32_t)__popcll(hits));
-      base = __shfl(base, 0);
-      if (base + (uint32_t)__popcll(hits) > P.bin_cap) {
-        if (lane == 0) atomicOr(&P.counters->overflow, 4u);
-        continue;
-      }
-      if (hit) {
-        uint32_t pos = base + (uint32_t)__popcll(hits & below);
-        P.pairs[pos] = make_uint2(bin, r);
-        P.pair_slot[pos] = slot;
-      }
+      bin = binbase + (uint32_t)ty * P.tiles_x + (uint32_t)tx;
+    }
+    unsigned long long hits = __ballot(hit);
+    if (!hits) continue;
+    uint32_t slot = 0, base = 0;
+    if (hit) slot = atomicAdd(&P.tile_count[bin], 1u);
+    if (lane == 0) base = atomicAdd(&P.counters->n_pairs_rest, (uint32_t)__popcll(hits));
+    base = __shfl(base, 0);
+    if ((unsigned long long)n_setup + base + (uint32_t)__popcll(hits) > P.bin_cap) {
+      if (lane == 0) atomicOr(&P.counters->overflow, 4u);
+      continue;
+    }
+    if (hit) {
+      uint32_t pos = P.bin_cap - 1u - (base + (uint32_t)__popcll(hits & below));
+      P.pairs[pos] = make_uint2(bin, r);
+      P.pair_slot[pos] = slot;
     }
   }
 }
 
-// Blocks [0, rest_blocks): the rest (above).  The others: one lane per pair the setup kernel emitted,
+// The triangles over 16 tiles the setup kernel queued instead of deciding their tiles lane by lane: one WAVE per record.
+__device__ __forceinline__ void bin_big(const FrameParams& P, uint32_t first_wave, uint32_t n_waves) {
+  const uint32_t n_big = min(P.counters->n_big, P.n_tris), n_setup = min(P.counters->n_pairs, P.bin_cap);
+  for (uint32_t it = first_wave; it < n_big; it += n_waves) {
+    const uint32_t r = P.big_queue[it];
+    const TriRec* rec = P.recs + r;
+    RecBox b = load_box(rec);
+    if (!b.valid) continue;  // wave-uniform
+    bin_one(P, r, b.minx, b.miny, b.maxx, b.maxy, (b.flags & F_TRANSPARENT) ? P.n_tiles : 0u, load_edges(rec), n_setup);
+  }
+}
+
+// The clipper, in the binning launch: the few triangles that cross the near / far planes or the guard band (a few
+// hundred per frame) were queued by the setup kernel.  CLIP_LANES lanes of a wave take one each — Sutherland-Hodgman
+// with the polygon in LDS (indexed by run-time values: as a local array it would live in scratch memory, and a kernel
+// with a scratch frame pays ~2.5 us at every dispatch, tools/gapbench.hip) — and emit the fan piece by piece, in step;
+// after every step the WHOLE wave bins the pieces just made, from their bounding boxes and edges in LDS (what
+// setup_triangle hands out beside the record), so nothing waits for the records to come back from memory.  Until round 3
+// this was a kernel of its own between setup and count, whose "rest" blocks then read the pieces back: one launch,
+// one boundary and ~5 us of a small pass's chain more.
+constexpr uint32_t CLIP_LANES = 8;
+struct ClipLds {
+  VOut poly[CLIP_LANES][12];
+  VOut tmp[CLIP_LANES][12];
+  TriGeom geom[CLIP_LANES];
+};
+__device__ __forceinline__ void clip_and_bin(const FrameParams& P, ClipLds& L, uint32_t block, uint32_t n_blocks) {
+  const uint32_t lane = threadIdx.x;  // wave 0 of the block
+  const uint32_t n = min(P.counters->n_clip, P.clip_cap), n_setup = min(P.counters->n_pairs, P.bin_cap);
+  const float hw = (float)P.W * 0.5f, hh = (float)P.H * 0.5f;
+  for (uint32_t q0 = block * CLIP_LANES; q0 < n; q0 += n_blocks * CLIP_LANES) {  // wave-uniform
+    const uint32_t q = q0 + lane;
+    const bool worker = lane < CLIP_LANES && q < n;
+    VOut* poly = L.poly[lane & (CLIP_LANES - 1u)];
+    int np = 0;
+    uint32_t first = 0, want = 0, used = 0, seq = 0, draw = 0;
+    if (worker) {
+      ClipItem it = P.clip_queue[q];
+      draw = it.draw;
+      const DrawDesc& d = P.draws[draw];
+      const uint32_t kind = (d.flags >> F_KIND_SHIFT) & 3u;
+      seq = d.tri_base + it.tri;
+      if (kind == PIPE_COLORED_TRIANGLE) {
+        colored_triangle_vert(0, poly[0]);
+        colored_triangle_vert(1, poly[1]);
+        colored_triangle_vert(2, poly[2]);
+      } else {
+        for (int k = 0; k < 3; k++) shade_corner(d, kind, d.mvp, d.idx[3 * it.tri + k], poly[k]);
+      }
+      np = clip_polygon(poly, L.tmp[lane], 3);
+      if (np >= 3) {
+        // The fan's records are one contiguous block, and the parent's (invalid) main slot links to it:
+        // the tile kernel's visibility pass keeps only (depth, key) per pixel and (key >> 2) - 1 names the main
+        // slot, so shading finds a clipped parent's covering piece through this link.
+        want = (uint32_t)(np - 2);
+        first = atomicAdd(&P.counters->n_extra, want);
+        if (first + want > P.extra_cap) {
+          atomicOr(&P.counters->overflow, 2u);
+          np = 0;
+        }
+      }
+    }
+    int steps = np;  // the longest fan of the wave's polygons
+    for (int m = 1; m < (int)CLIP_LANES; m <<= 1) steps = max(steps, __shfl_xor(steps, m));
+    steps = __shfl(steps, 0);
+    for (int i = 1; i + 1 < steps; i++) {  // wave-uniform
+      bool made = false;
+      uint32_t rec = 0, transparent = 0;
+      if (worker && i + 1 < np) {
+        const DrawDesc& d = P.draws[draw];
+        ScreenV s0 = to_screen(poly[0].clip, hw, hh), s1 = to_screen(poly[i].clip, hw, hh), s2 = to_screen(poly[i + 1].clip, hw, hh);
+        if (s0.ok && s1.ok && s2.ok && poly[0].clip[3] > 0.0f && poly[i].clip[3] > 0.0f && poly[i + 1].clip[3] > 0.0f) {
+          // the record is written where it goes (no staging in registers: sixteen more live uint4 put the kernel over its
+          // register cap); a piece that turns out degenerate leaves a slot that the next one, or store_invalid below, overwrites
+          rec = P.n_tris + first + used;
+          uint4* dst = reinterpret_cast<uint4*>(P.recs + rec);
+          if (setup_triangle(P, &poly[0], &poly[i], &poly[i + 1], s0, s1, s2, make_key(seq, d.flags, P.tex[d.tex], true), d.flags, P.tex[d.tex],
+                             *reinterpret_cast<uint4(*)[16]>(dst), &L.geom[lane])) {
+            made = true;
+            used++;
+            transparent = (d.flags & F_TRANSPARENT) ? 1u : 0u;
+            if (P.instrument) atomicAdd(&P.counters->binned, 1ull);
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // the pieces' boxes and edges are in LDS: every lane may read them
+      for (unsigned long long todo = __ballot(made); todo; todo &= todo - 1ull) {
+        const int l = __ffsll((long long)todo) - 1;
+        const TriGeom& gm = L.geom[l];
+        EdgeSet e;
+        e.A0 = gm.A[0]; e.A1 = gm.A[1]; e.A2 = gm.A[2]; e.B0 = gm.B[0]; e.B1 = gm.B[1]; e.B2 = gm.B[2];
+        e.C0 = gm.C[0]; e.C1 = gm.C[1]; e.C2 = gm.C[2];
+        bin_one(P, (uint32_t)__shfl((int)rec, l), gm.minx, gm.miny, gm.maxx, gm.maxy, __shfl((int)transparent, l) ? P.n_tiles : 0u, e, n_setup);
+      }
+      __builtin_amdgcn_wave_barrier();  // ... before the next step's pieces overwrite them
+    }
+    if (worker && np >= 3) {
+      for (uint32_t k = used; k < want; k++) store_invalid(P.recs + P.n_tris + first + k);  // reserved, unused
+      uint4 link;
+      link.x = 1u;  // minx = 1 > maxx = 0: still an invalid record for binning
+      link.y = 0u;
+      link.z = P.n_tris + first;
+      link.w = used;
+      *reinterpret_cast<uint4*>(P.recs + seq) = link;
+    }
+  }
+}
+
+// Blocks [0, big_blocks): the queued big triangles (above).  [big_blocks, big_blocks + clip_blocks): the clipper (above;
+// wave 0 of each).  The others: one lane per pair the setup kernel emitted,
 // grid-stride; the lanes of a wave that target the same bin share ONE atomic (device-scope atomics run
 // at the memory side and serialise per line: unmerged, neighbouring triangles made binning
 // atomic-bound), and its return value is the pair's position in its bin — kept, so the fill is a plain
 // scatter with no second round of atomics.
-__global__ __launch_bounds__(256) void count_kernel(FrameParams P, uint32_t rest_blocks) {
+__global__ __launch_bounds__(256, 4) void count_kernel(FrameParams P, uint32_t big_blocks, uint32_t clip_blocks) {
+  __shared__ ClipLds s_clip;
   if (P.counters->overflow) return;  // a queue overflowed: the pass is void, the host grows it and replays
+  if (blockIdx.x < big_blocks) {
+    bin_big(P, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, (big_blocks * blockDim.x) >> 6);
+    return;
+  }
+  const uint32_t rest_blocks = big_blocks + clip_blocks;
   if (blockIdx.x < rest_blocks) {
-    bin_rest(P, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, (rest_blocks * blockDim.x) >> 6);
+    if (threadIdx.x < 64u) clip_and_bin(P, s_clip, blockIdx.x - big_blocks, clip_blocks);
     return;
   }
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long below = (1ull << lane) - 1ull;
-  const uint32_t n = P.counters->n_pairs_setup, rounded = (n + 63u) & ~63u;
+  const uint32_t n = min(P.counters->n_pairs, P.bin_cap), rounded = (n + 63u) & ~63u;
   const uint32_t stride = (gridDim.x - rest_blocks) * blockDim.x;
   for (uint32_t i = (blockIdx.x - rest_blocks) * blockDim.x + threadIdx.x; i < rounded; i += stride) {
     bool has = i < n;
@@ -222,7 +330,7 @@ __global__ __launch_bounds__(256) void fill_kernel(FrameParams P) {
       // a transparent bin too large for the tile kernel's LDS sort gets a span of the global sort arena
       // (next power of two: the bitonic network pads); failing here voids the pass before it draws
       uint32_t sort_base = 0;
-      if (n_tr > 2048u) {
+      if (n_tr > SPLIT_SORT_MAX) {  // (= the tile kernel's SORT_CAP)
         uint32_t np = 1u << (32 - __clz(n_tr - 1u));
         sort_base = atomicAdd(&P.counters->sort_used, np);
         if (sort_base + np > P.sort_cap) atomicOr(&P.counters->overflow, 4u);
@@ -252,17 +360,19 @@ __global__ __launch_bounds__(256) void fill_kernel(FrameParams P) {
       P.tile_info[2u * (SPLIT_EXTRA + slot) + 1u] = make_uint4(off_tr, sort_base, 0u, split ? 1u : 0u);  // w: "rendered by its quarters"
     }
   }
-  const uint32_t n = min(P.counters->n_pairs, P.bin_cap);
-  for (uint32_t i = t; i < n; i += gridDim.x * blockDim.x) {
-    uint2 p = P.pairs[i];
-    uint32_t pos = P.tile_offset[p.x] + P.pair_slot[i];
+  // the setup kernel's pairs at the head of the list, the count launch's own (big triangles, clipper pieces) at its tail
+  const uint32_t n = min(P.counters->n_pairs, P.bin_cap), n_rest = min(P.counters->n_pairs_rest, P.bin_cap - n);
+  for (uint32_t i = t; i < n + n_rest; i += gridDim.x * blockDim.x) {
+    const uint32_t at = i < n ? i : P.bin_cap - 1u - (i - n);
+    uint2 p = P.pairs[at];
+    uint32_t pos = P.tile_offset[p.x] + P.pair_slot[at];
     if (pos < P.bin_cap) P.bins[pos] = p.y;
   }
 }
 
 void launch_bin_count(const FrameParams& P, hipStream_t s) {
-  const uint32_t rest_blocks = 128;
-  hipLaunchKernelGGL(count_kernel, dim3(rest_blocks + 1024u), dim3(256), 0, s, P, rest_blocks);
+  const uint32_t big_blocks = 128, clip_blocks = 512;
+  hipLaunchKernelGGL(count_kernel, dim3(big_blocks + clip_blocks + 1024u), dim3(256), 0, s, P, big_blocks, clip_blocks);
 }
 void launch_bin_scan(const FrameParams& P, hipStream_t s) {
   hipLaunchKernelGGL(offsets_kernel, dim3((2u * P.n_tiles + 255u) / 256u), dim3(256), 0, s, P);

@@ -9,22 +9,15 @@
 // the run of the vertex buffer its 192 indices touch, consecutive lanes read consecutive 48-byte vertices —
 // run through mesh.vert ONCE each and parked in LDS for the chunk's triangles to pick up (runs longer than 128
 // vertices fall back to a gather per corner); no post-transform buffer goes through memory.  Triangles that
-// need real clipping (any vertex beyond the near/far planes or the guard band) are queued and handled by
-// clip_kernel so this kernel keeps no polygon arrays in scratch.
+// need real clipping (any vertex beyond the near/far planes or the guard band) are queued and handled by the
+// clipper blocks of the binning launch (k_bin.hip clip_and_bin) so this kernel keeps no polygon arrays in scratch.
 #include <algorithm>
 
 #include "svr_bin.h"
+#include "svr_clip.h"
 #include "svr_launch.h"
 
 namespace svr {
-
-__device__ __forceinline__ void shade_corner(const DrawDesc& d, uint32_t kind, const float* mvp, uint32_t index, VOut& o) {
-  VertexRaw v = load_vertex(d.vtx, index);
-  if (kind == PIPE_MESH)
-    mesh_vert(v, mvp, d.mat, d.color_factors, o);
-  else
-    colored_triangle_mesh_vert(v, d.mat, o);
-}
 
 // Can any fragment of the box [lo, hi] (object space) under clip = mvp * (p, 1) land inside the scissor?  Half-space
 // tests in clip space, no division: every visible point lies inside the clip volume (w > 0 there), where
@@ -45,7 +38,34 @@ __device__ __forceinline__ bool chunk_can_be_seen(const FrameParams& P, const fl
   const bool gone = (__ballot(out_near) & corners) == corners || (__ballot(out_far) & corners) == corners ||
                     (__ballot(out_l) & corners) == corners || (__ballot(out_r) & corners) == corners ||
                     (__ballot(out_t) & corners) == corners || (__ballot(out_b) & corners) == corners;
-  return !gone;
+  if (gone) return false;
+  if (P.rstride > 1u) {
+    // Interleaved rows (a rank of the multi-GPU form owns every rstride-th tile row and runs the WHOLE scene's vertex
+    // stage): a chunk whose box lies in front of the eye (every corner w > 0: its image is inside the hull of the
+    // corners' images) and between two of the rank's tile rows goes no further.  One division per corner, the rows one
+    // pixel wider than the corners' images (snapping and rounding move a vertex by far less).  configs[4] at N = 8: a
+    // chunk of 64 triangles spans about three tile rows, so three chunks of five stop here.
+    const bool front = (__ballot(c[3] > 0.0f) & corners) == corners;
+    if (front) {
+      float ys = (c[1] / c[3] + 1.0f) * (0.5f * (float)P.H);
+      float lo_y = ys, hi_y = ys;
+#pragma unroll
+      for (int m = 1; m < 8; m <<= 1) {  // lanes 0..7 hold the corners: their partners under xor 1, 2, 4 are corners too
+        lo_y = fminf(lo_y, __shfl_xor(lo_y, m));
+        hi_y = fmaxf(hi_y, __shfl_xor(hi_y, m));
+      }
+      lo_y = __shfl(lo_y, 0);
+      hi_y = __shfl(hi_y, 0);
+      if (lo_y == lo_y && hi_y == hi_y && fabsf(lo_y) < 1.0e6f && fabsf(hi_y) < 1.0e6f) {  // (NaNs and wild values never cull)
+        int miny = max((int)floorf(lo_y) - 1, (int)P.sy), maxy = min((int)ceilf(hi_y) + 1, (int)(P.sy + P.sh) - 1);
+        if (miny > maxy) return false;
+        int l0, l1;
+        local_tile_rows(P, miny, maxy, l0, l1);
+        if (l0 > l1) return false;
+      }
+    }
+  }
+  return true;
 }
 
 __global__ __launch_bounds__(256, 4) void setup_kernel(FrameParams P) {
@@ -223,108 +243,6 @@ __global__ __launch_bounds__(256, 4) void setup_kernel(FrameParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float plane_dist(int plane, const float* c) {
-  switch (plane) {
-    case 0: return c[3] - c[2];
-    case 1: return c[2];
-    case 2: return c[3] + c[0];
-    case 3: return c[3] - c[0];
-    case 4: return c[3] + c[1];
-    default: return c[3] - c[1];
-  }
-}
-
-// Sutherland-Hodgman against the six planes (C2); new vertices always interpolate inside -> outside.
-// poly, tmp: room for 12 vertices each (LDS in clip_kernel: indexed by run-time values they would otherwise live in scratch)
-__device__ int clip_polygon(VOut* poly, VOut* tmp, int n) {
-  for (int plane = 0; plane < 6 && n >= 3; plane++) {
-    int m = 0;
-    for (int i = 0; i < n; i++) {
-      const VOut& a = poly[i];
-      const VOut& b = poly[(i + 1 == n) ? 0 : i + 1];
-      float da = plane_dist(plane, a.clip), db = plane_dist(plane, b.clip);
-      bool ina = da >= 0.0f, inb = db >= 0.0f;
-      if (ina) tmp[m++] = a;
-      if (ina != inb) {
-        const VOut& pin = ina ? a : b;
-        const VOut& pout = ina ? b : a;
-        float din = ina ? da : db, dout = ina ? db : da;
-        float t = din / (din - dout);
-        VOut nv;
-        for (int k = 0; k < 4; k++) nv.clip[k] = fmaf(t, pout.clip[k] - pin.clip[k], pin.clip[k]);
-        for (int k = 0; k < 8; k++) nv.attr[k] = fmaf(t, pout.attr[k] - pin.attr[k], pin.attr[k]);
-        tmp[m++] = nv;
-      }
-    }
-    n = m;
-    for (int i = 0; i < n; i++) poly[i] = tmp[i];
-  }
-  return n >= 3 ? n : 0;
-}
-
-// One lane per queued triangle, grid-stride over the device-side queue length; CLIP_LANES lanes of the wave work.
-// The polygon under the knife is indexed by run-time values: as a local array it lives in scratch memory, and a kernel
-// with a scratch frame pays ~2.5 us at every dispatch (tools/gapbench.hip) — on the chain that bounds small passes.
-// It lives in LDS instead, 1152 bytes per working lane (eight lanes: with more LDS per workgroup than 10 KiB the compiler drops the
-// 128-VGPR cap of __launch_bounds__(64, 4), and a stage-1 wave above 128 waits for two tile-kernel waves to retire); the queue
-// holds a few hundred triangles per frame.
-constexpr uint32_t CLIP_LANES = 8;
-__global__ __launch_bounds__(64, 4) void clip_kernel(FrameParams P) {
-  __shared__ VOut s_poly[CLIP_LANES][12];
-  __shared__ VOut s_tmp[CLIP_LANES][12];
-  // the setup kernel is complete (stream order): freeze the length of its part of the pair list
-  if (blockIdx.x == 0 && threadIdx.x == 0) P.counters->n_pairs_setup = min(P.counters->n_pairs, P.bin_cap);
-  if (threadIdx.x >= CLIP_LANES) return;
-  uint32_t n = min(P.counters->n_clip, P.clip_cap);
-  float hw = (float)P.W * 0.5f, hh = (float)P.H * 0.5f;
-  VOut* poly = s_poly[threadIdx.x];
-  for (uint32_t q = blockIdx.x * CLIP_LANES + threadIdx.x; q < n; q += gridDim.x * CLIP_LANES) {
-    ClipItem it = P.clip_queue[q];
-    const DrawDesc& d = P.draws[it.draw];
-    uint32_t kind = (d.flags >> F_KIND_SHIFT) & 3u;
-    uint32_t seq = d.tri_base + it.tri;
-    if (kind == PIPE_COLORED_TRIANGLE) {
-      colored_triangle_vert(0, poly[0]);
-      colored_triangle_vert(1, poly[1]);
-      colored_triangle_vert(2, poly[2]);
-    } else {
-      for (int k = 0; k < 3; k++) shade_corner(d, kind, d.mvp, d.idx[3 * it.tri + k], poly[k]);
-    }
-    int np = clip_polygon(poly, s_tmp[threadIdx.x], 3);
-    if (np < 3) continue;
-    // The fan's records are one contiguous block, and the parent's (invalid) main slot links to it:
-    // the tile kernel's visibility pass keeps only (depth, key) per pixel and (key >> 2) - 1 names the main
-    // slot, so shading finds a clipped parent's covering piece through this link.
-    uint32_t want = (uint32_t)(np - 2);
-    uint32_t first = atomicAdd(&P.counters->n_extra, want);
-    if (first + want > P.extra_cap) {
-      atomicOr(&P.counters->overflow, 2u);
-      continue;
-    }
-    uint32_t used = 0;
-    for (int i = 1; i + 1 < np; i++) {
-      ScreenV s0 = to_screen(poly[0].clip, hw, hh), s1 = to_screen(poly[i].clip, hw, hh),
-              s2 = to_screen(poly[i + 1].clip, hw, hh);
-      if (!(s0.ok && s1.ok && s2.ok)) continue;
-      if (!(poly[0].clip[3] > 0.0f && poly[i].clip[3] > 0.0f && poly[i + 1].clip[3] > 0.0f)) continue;
-      // the record is written where it goes (no staging in registers: sixteen more live uint4 put the kernel over its
-      // register cap); a piece that turns out degenerate leaves a slot that the next one, or store_invalid below, overwrites
-      uint4* dst = reinterpret_cast<uint4*>(P.recs + P.n_tris + first + used);
-      if (!setup_triangle(P, &poly[0], &poly[i], &poly[i + 1], s0, s1, s2, make_key(seq, d.flags, P.tex[d.tex], true), d.flags, P.tex[d.tex], *reinterpret_cast<uint4(*)[16]>(dst), nullptr)) continue;
-      used++;
-      if (P.instrument) atomicAdd(&P.counters->binned, 1ull);
-    }
-    for (uint32_t k = used; k < want; k++) store_invalid(P.recs + P.n_tris + first + k);  // reserved, unused
-    uint4 link;
-    link.x = 1u;  // minx = 1 > maxx = 0: still an invalid record for binning
-    link.y = 0u;
-    link.z = P.n_tris + first;
-    link.w = used;
-    *reinterpret_cast<uint4*>(P.recs + seq) = link;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // mesh.vert as a stand-alone operator: one vertex per lane, three coalesced 16-byte loads per lane
 // (a wave reads 3 KiB contiguous), writes gl_Position and the 8 varyings.
 __global__ __launch_bounds__(256) void mesh_vert_kernel(const SvrVertex* vtx, uint32_t first, uint32_t n,
@@ -405,9 +323,6 @@ void launch_prologue(const void* host_src, void* dst, size_t copy_bytes, void* z
   uint32_t blocks = std::min<uint32_t>(256u, (std::max(n_copy, n_zero) + 255u) / 256u);
   hipLaunchKernelGGL(prologue_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, s, (const uint4*)host_src, (uint4*)dst, n_copy,
                      (uint4*)zero, n_zero, n_draws, scene);
-}
-void launch_clip(const FrameParams& P, hipStream_t s) {
-  hipLaunchKernelGGL(clip_kernel, dim3(512), dim3(64), 0, s, P);
 }
 void launch_mesh_vert(const SvrVertex* vtx, uint32_t first, uint32_t n, const float* world16,
                       const float* viewproj16, const float* color_factors4, float* out_clip,

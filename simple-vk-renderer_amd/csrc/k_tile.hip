@@ -19,7 +19,7 @@
 //            specialised instance serves waves whose pixels all carry the key's common-case bit
 //   phase C  transparent bin sorted by key in LDS, banded column scan (wave w owns rows 8w..8w+7) that
 //            appends depth-passing fragments to per-wave queues in submission order, shaded 64 at a
-//            time, blended at target precision; bins over 2048 entries sort in a global arena instead
+//            time, blended at target precision; bins over SORT_CAP (1408) entries sort in a global arena instead
 //   phase D  write-back: whole tiles go out through LDS as full rows, the depth CLEAR and a deferred
 //            svr_clear_color are fused here
 // Heavy tiles of small passes are rendered as four 8-row quarters by four workgroups (tile_kernel<.., SPLIT>).
@@ -425,7 +425,7 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
 
 // (key >> 2) - 1 is the main record slot, and for keys with bit 0 clear that is the record.  Bit 0 set:
 // the triangle went through the clipper, its slot is an invalid record that links to the contiguous
-// block of its pieces (k_geometry.hip clip_kernel); exactly one of them covers the pixel (they
+// block of its pieces (k_bin.hip clip_and_bin); exactly one of them covers the pixel (they
 // partition the parent under the top-left rule).  The flag keeps this dependent load out of the
 // common path.
 __device__ __forceinline__ uint32_t resolve_record(const FrameParams& P, uint32_t rec, int px, int py) {
@@ -454,14 +454,14 @@ __device__ __forceinline__ uint32_t resolve_record(const FrameParams& P, uint32_
 // blended into the wave's LDS colour band.  Several fragments of one pixel can sit in the same group
 // of 64: the lowest lane of every pixel applies them in lane order = queue order (flush_fragments).
 // In a quarter of a split tile (svr_device.h SPLIT_*) a wave owns 2 rows instead of 8.
-constexpr uint32_t SORT_CAP = 2048;                       // bins above this are sorted in the global sort arena instead of LDS
+constexpr uint32_t SORT_CAP = SPLIT_SORT_MAX;             // (1408) bins above this are sorted in the global sort arena instead of LDS
 constexpr uint32_t RANK_SORT_MAX = 1024;                  // bins up to this are ranked on their 32-bit keys (rank_sort), up to SORT_CAP by rank_sort_big
-constexpr uint32_t QUARTER_LIST_CAP = 5120;               // entries of a quarter's row-filtered opaque list (LDS behind the depth tile)
+constexpr uint32_t QUARTER_LIST_CAP = 3840;               // entries of a quarter's row-filtered opaque list (LDS behind the depth tile); bins are taken in windows of this
 constexpr uint32_t QUEUE_CAP = 128;                       // < 64 carried over + up to 64 new per row step
 
 template <int FMT, bool INSTR>
 __device__ __forceinline__ void flush_fragments(const FrameParams& P, typename Codec<FMT>::enc_t* col, uint2* q,
-                                                unsigned long long* mask, float4* s_src, uint32_t& qn, int tx0, int by0,
+                                                float4* s_src, uint32_t& qn, int tx0, int by0,
                                                 uint32_t lane, uint32_t& n_shaded) {
   typedef Codec<FMT> CD;
   uint32_t cnt = min(qn, 64u);
@@ -475,15 +475,24 @@ __device__ __forceinline__ void flush_fragments(const FrameParams& P, typename C
     if (INSTR) n_shaded++;
   }
   // Blending is ordered per pixel (C13) and a group of 64 queued fragments often holds many layers of
-  // the same few pixels (a curtain seen edge-on).  Every pixel's fragments are collected as a lane mask
-  // (one LDS atomic), and the lowest lane of each mask blends its pixel's fragments in lane order =
-  // submission order, in registers: one LDS read per layer instead of an election round per layer.
-  if (act) {
-    s_src[lane] = src;
-    atomicOr(&mask[pix], 1ull << lane);
+  // the same few pixels (a curtain seen edge-on).  Every pixel's fragments are collected as a lane mask,
+  // and the lowest lane of each mask blends its pixel's fragments in lane order = submission order, in
+  // registers: one LDS read per layer instead of an election round per layer.  The masks come from eight
+  // ballots, one per bit of the pixel's number in the wave's band (pix < 256): a lane keeps, bit by bit, the lanes
+  // that agree with it — some fifty instructions per group of 64 fragments whatever it holds.  (A 64-bit word
+  // per pixel of the band in LDS, filled by atomics, was 8 KiB of the workgroup's 37: the difference between four
+  // and five workgroups per CU.  One ballot per DISTINCT pixel was tried first: up to 64 rounds per group, as
+  // long as the fragment stage itself.)
+  if (act) s_src[lane] = src;
+  unsigned long long mm = __ballot(act);
+#pragma unroll
+  for (uint32_t b = 0; b < 8u; b++) {
+    const bool bit = (pix >> b) & 1u;
+    const unsigned long long with = __ballot(bit);
+    mm &= bit ? with : ~with;
   }
+  mm = act ? mm : 0ull;
   __builtin_amdgcn_wave_barrier();  // LDS operations of a wave retire in order; this pins the compiler's order too
-  unsigned long long mm = act ? mask[pix] : 0ull;
   if (act && (mm & ((1ull << lane) - 1ull)) == 0ull) {
     float4 dst = CD::decode(col[pix]);
     typename CD::enc_t out = col[pix];
@@ -503,7 +512,6 @@ __device__ __forceinline__ void flush_fragments(const FrameParams& P, typename C
       dst = CD::decode(out);  // the attachment holds the rounded value between layers
     }
     col[pix] = out;
-    mask[pix] = 0ull;
   }
   uint32_t rest = qn - cnt;
   for (uint32_t j = lane; j < rest; j += 64u) {  // lock-step: every read of a step precedes its writes
@@ -540,7 +548,7 @@ __device__ __forceinline__ bool block_any(bool v, uint32_t wv) {
 template <int FMT, bool INSTR>
 __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4* s_cov, uint32_t* s_idx, const uint32_t* order,
                                                      uint32_t n, int tx0, int ty0, int row0, uint32_t lrpw, const uint32_t* s_z,
-                                                     typename Codec<FMT>::enc_t* col, uint2* q, unsigned long long* mask, float4* s_src,
+                                                     typename Codec<FMT>::enc_t* col, uint2* q, float4* s_src,
                                                      uint32_t& n_raster, uint32_t& n_shaded, const uint32_t wv) {
   const uint32_t tid = tid_of(wv), lane = tid & 63u, wave = wv;
   const unsigned long long below = (1ull << lane) - 1ull;
@@ -586,59 +594,82 @@ __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4
       if ((int)lane >= off) inc += v;
     }
     uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-    for (uint32_t c = 0; c * 64u < total; c++) {  // every chunk, in order: items are sorted by submission key
-      uint32_t j = c * 64u + lane;
-      bool act = j < total;
-      uint32_t pos = 0;
+    // The scan is RESUMABLE: it runs until the wave's queue holds a full group of 64 fragments, stops, the group is
+    // shaded, and the scan takes up again at (chunk c, row t) — a wave-uniform pair; everything else about a lane's
+    // item is made again from the staged records.  Shading inside the row loop kept the whole scan state (edge
+    // values and increments in fp64, the z plane, the item's coordinates: some forty registers) alive across the
+    // inlined fragment stage: 124 VGPRs, four waves per SIMD, for a phase 1.5 % of the tiles run.
+    uint32_t c = 0;
+    int t = 0;
+    for (;;) {
+      bool full = false;
+      while (c * 64u < total) {  // every chunk, in order: items are sorted by submission key
+        uint32_t j = c * 64u + lane;
+        bool act = j < total;
+        uint32_t pos = 0;
 #pragma unroll
-      for (uint32_t step = 32; step >= 1; step >>= 1) {
-        uint32_t v = __shfl(inc, (int)min(pos + step - 1u, 63u));
-        if (pos + step <= 64u && v <= j) pos += step;
-      }
-      uint32_t i = min(pos, 63u);
-      uint32_t excl = __shfl(inc, (int)i) - (uint32_t)__shfl(cw, (int)i);
-      int colx = __shfl(cx0, (int)i) + (int)(j - excl) - tx0;  // column inside the tile
-      colx = act ? colx : 0;
-      const uint4* rec = s_cov + i * 8u;
-      uint4 h = rec[0];
-      int y0 = (int)(int16_t)(h.x >> 16), y1 = (int)(int16_t)(h.y >> 16);
-      uint32_t flags = h.w, ri = s_idx[i];
-      float4 zr = reinterpret_cast<const float4*>(rec)[1];
-      const double2* d = reinterpret_cast<const double2*>(rec);
-      double2 c2 = d[2], c3 = d[3], c4 = d[4], c5 = d[5], c6 = d[6];
-      double B0 = c3.y, B1 = c4.x, B2 = c4.y;
-      double dx = (double)(tx0 + colx), dy = (double)by0;
-      double f0 = fma(c2.x, dx, fma(B0, dy, c5.x));
-      // edges 1 and 2 are walked UNBIASED (g = f + 1 where C carries the top-left bias, else f): that is the value the
-      // barycentrics want, and for integers "f >= 0" is "g > 0" there and "g >= 0" elsewhere — two compares where
-      // holding the two 1.0 / 0.0 in registers across walk and flush cost four VGPRs and an add per row
-      // (walking edges 1 and 2 unbiased, with "g > 0" / "g >= 0" picked per lane, saves the two adds and four
-      // registers below but pays more in the compares' mask logic: +4 % on the curtain tiles)
-      const double u1 = (flags & F_T1) ? 1.0 : 0.0, u2 = (flags & F_T2) ? 1.0 : 0.0;
-      double g1 = fma(c2.y, dx, fma(B1, dy, c5.y));
-      double g2 = fma(c3.x, dx, fma(B2, dy, c6.x));
-#pragma unroll 1
-      for (int t = 0; t < rpw; t++) {  // the same absolute row by0 + t in every lane
-        int y = by0 + t;
-        bool inside = act && y >= y0 && y <= y1 && f0 >= 0.0 && g1 >= 0.0 && g2 >= 0.0;
-        if (INSTR) n_raster += inside ? 1u : 0u;
-        float b1 = (float)(g1 + u1) * zr.w, b2 = (float)(g2 + u2) * zr.w;
-        float z = fmaf(b2, zr.z, fmaf(b1, zr.y, zr.x));
-        z = fminf(fmaxf(z, 0.0f), 1.0f) + 0.0f;
-        bool pass = inside && f2u(z) >= s_z[(y - ty0) * TILE + colx];  // GREATER_OR_EQUAL vs opaque depth, no write
-        unsigned long long m = __ballot(pass);
-        if (m) {
-          if (pass) q[qn + (uint32_t)__popcll(m & below)] = make_uint2((uint32_t)(t * TILE + colx), ri);
-          qn += (uint32_t)__popcll(m);
-          if (qn >= 64u) flush_fragments<FMT, INSTR>(P, col, q, mask, s_src, qn, tx0, by0, lane, n_shaded);
+        for (uint32_t step = 32; step >= 1; step >>= 1) {
+          uint32_t v = __shfl(inc, (int)min(pos + step - 1u, 63u));
+          if (pos + step <= 64u && v <= j) pos += step;
         }
-        f0 += B0;
-        g1 += B1;
-        g2 += B2;
+        uint32_t i = min(pos, 63u);
+        uint32_t excl = __shfl(inc, (int)i) - (uint32_t)__shfl(cw, (int)i);
+        int colx = __shfl(cx0, (int)i) + (int)(j - excl) - tx0;  // column inside the tile
+        colx = act ? colx : 0;
+        const uint4* rec = s_cov + i * 8u;
+        uint4 h = rec[0];
+        int y0 = (int)(int16_t)(h.x >> 16), y1 = (int)(int16_t)(h.y >> 16);
+        uint32_t flags = h.w, ri = s_idx[i];
+        float4 zr = reinterpret_cast<const float4*>(rec)[1];
+        const double2* d = reinterpret_cast<const double2*>(rec);
+        double2 c2 = d[2], c3 = d[3], c4 = d[4], c5 = d[5], c6 = d[6];
+        double B0 = c3.y, B1 = c4.x, B2 = c4.y;
+        double dx = (double)(tx0 + colx), dy = (double)(by0 + t);  // (exact integers below 2^53: the same values the row-by-row additions reach)
+        double f0 = fma(c2.x, dx, fma(B0, dy, c5.x));
+        // edges 1 and 2 are walked UNBIASED (g = f + 1 where C carries the top-left bias, else f): that is the value the
+        // barycentrics want, and for integers "f >= 0" is "g > 0" there and "g >= 0" elsewhere — two compares where
+        // holding the two 1.0 / 0.0 in registers across walk and flush cost four VGPRs and an add per row
+        // (walking edges 1 and 2 unbiased, with "g > 0" / "g >= 0" picked per lane, saves the two adds and four
+        // registers below but pays more in the compares' mask logic: +4 % on the curtain tiles)
+        const double u1 = (flags & F_T1) ? 1.0 : 0.0, u2 = (flags & F_T2) ? 1.0 : 0.0;
+        double g1 = fma(c2.y, dx, fma(B1, dy, c5.y));
+        double g2 = fma(c3.x, dx, fma(B2, dy, c6.x));
+#pragma unroll 1
+        for (; t < rpw; t++) {  // the same absolute row by0 + t in every lane
+          int y = by0 + t;
+          bool inside = act && y >= y0 && y <= y1 && f0 >= 0.0 && g1 >= 0.0 && g2 >= 0.0;
+          if (INSTR) n_raster += inside ? 1u : 0u;
+          float b1 = (float)(g1 + u1) * zr.w, b2 = (float)(g2 + u2) * zr.w;
+          float z = fmaf(b2, zr.z, fmaf(b1, zr.y, zr.x));
+          z = fminf(fmaxf(z, 0.0f), 1.0f) + 0.0f;
+          bool pass = inside && f2u(z) >= s_z[(y - ty0) * TILE + colx];  // GREATER_OR_EQUAL vs opaque depth, no write
+          unsigned long long m = __ballot(pass);
+          f0 += B0;
+          g1 += B1;
+          g2 += B2;
+          if (m) {
+            if (pass) q[qn + (uint32_t)__popcll(m & below)] = make_uint2((uint32_t)(t * TILE + colx), ri);
+            qn += (uint32_t)__popcll(m);
+            if (qn >= 64u) {  // stop here: the group is shaded with none of the above alive
+              full = true;
+              t++;
+              break;
+            }
+          }
+        }
+        if (full) break;
+        t = 0;
+        c++;
+      }
+      if (!full) break;  // the batch is exhausted
+      flush_fragments<FMT, INSTR>(P, col, q, s_src, qn, tx0, by0, lane, n_shaded);
+      if (t == rpw) {
+        t = 0;
+        c++;
       }
     }
   }
-  while (qn) flush_fragments<FMT, INSTR>(P, col, q, mask, s_src, qn, tx0, by0, lane, n_shaded);
+  while (qn) flush_fragments<FMT, INSTR>(P, col, q, s_src, qn, tx0, by0, lane, n_shaded);
 }
 
 // Rank by counting: with unique keys the number of smaller keys IS the sorted position.  Every lane reads the
@@ -729,7 +760,7 @@ __device__ __forceinline__ void rank_pass(const uint32_t* k32, const uint32_t* r
   }
 }
 
-// Bins of 1025 .. 2048 entries: the same rank by counting with keys AND record indices parked in LDS, every thread
+// Bins of 1025 .. SORT_CAP entries: the same rank by counting with keys AND record indices parked in LDS, every thread
 // taking its eight elements four at a time (eight keys, records and ranks per thread at once were the register
 // peak of the whole kernel, paid for by spills in the phases every tile runs).  Ties (the clipper's pieces of one
 // triangle sharing the tile) leave a rank unclaimed; such a bin is ranked again on (key, position in the bin) —
@@ -793,7 +824,7 @@ __device__ __forceinline__ void rank_sort_big(const FrameParams& P, unsigned cha
 // scan sees the same fragments in the same order.  (Every quarter used to sort the whole bin and walk all of it: at
 // 1920x1080 the quarter of a tile that sees a curtain edge-on IS the frame — 1224 triangles, 232 K cycles in phase
 // C of which ~55 K the rank by counting, whose cost goes with the square of the list.)
-// lds: >= 16 KiB (keys, record indices); marks: [SORT_CAP] words elsewhere in LDS.  Returns the length of the list.
+// lds: >= 8 * SORT_CAP bytes (keys, record indices); marks: [SORT_CAP] words elsewhere in LDS.  Returns the length of the list.
 __device__ __forceinline__ uint32_t sort_quarter_bin(const FrameParams& P, unsigned char* lds, uint32_t* marks, uint32_t bin_base, uint32_t n,
                                                      int tx0, int qy0, int qrows, uint32_t* out, const uint32_t wv) {
   __shared__ uint32_t kept;
@@ -871,11 +902,11 @@ __device__ __forceinline__ uint32_t sort_quarter_bin(const FrameParams& P, unsig
   return m;
 }
 
-// s: scratch — the LDS block (>= 16 KiB) for bins up to SORT_CAP, else the tile's span of the global sort arena,
+// s: scratch — the LDS block (>= 8 * SORT_CAP bytes) for bins up to SORT_CAP, else the tile's span of the global sort arena,
 // the next power of two >= n words (fill_kernel reserved it; global memory is coherent inside a workgroup's CU).
 // out: where the sorted record indices go — the bin itself, or (quarters of a split tile, n <= RANK_SORT_MAX) the
 // tile's words of the sort arena, which all four quarters fill with the same values.
-// WIDE: bins of 1025 .. 2048 entries keep all eight elements of a thread in registers (rank_sort<5..8>) instead of
+// WIDE: bins of 1025 .. SORT_CAP entries keep all their (up to six) elements of a thread in registers (rank_sort<5..8>) instead of
 // going through rank_sort_big.  For the kernel built with the quarter path (passes of up to 4096 tiles: 1080p, the
 // row bands of a multi-GPU run) whose frame time IS its deepest curtain tile: 2.5 % of the 1080p frame; in the
 // whole-tile kernel the same choice costs the phases every tile runs more (registers) than it returns.
@@ -946,12 +977,14 @@ __device__ __forceinline__ void sort_bin_by_key(const FrameParams& P, unsigned l
 //              target's encoding — shaded pixels go straight there instead of living in registers until the
 //              write-back (with depth, keys and colours of four pixels per lane in VGPRs the kernel sat on the
 //              128-register line and every change to the fragment stage paid in scratch traffic)
-//   [8K, 12K)  the tile's opaque depth bits for phase C's depth test (phase A of a quarter: its triangle list, to 28K)
-//   [12K, 28K) phase C: sort scratch, then per wave its fragment queue | lane mask per pixel | shaded colours
+//   [8K, 12K)  the tile's opaque depth bits for phase C's depth test (phase A of a quarter: its triangle list, to the end)
+//   [12K, 23K) phase C: sort scratch (11 KiB), then per wave its fragment queue | shaded colours (2 KiB each)
 constexpr uint32_t LDS_Z_OFF = TILE * TILE * 8;
 constexpr uint32_t LDS_C_OFF = LDS_Z_OFF + TILE * TILE * 4;
-constexpr uint32_t WAVE_C_BYTES = QUEUE_CAP * 8 + 256 * 8 + 64 * 16;  // queue | lane mask per pixel | shaded colours
-constexpr uint32_t PHASE_C_BYTES = LDS_C_OFF + 4 * WAVE_C_BYTES;
+constexpr uint32_t WAVE_C_BYTES = QUEUE_CAP * 8 + 64 * 16;  // queue | shaded colours
+// the four waves' blocks, or the sort's scratch (keys + record indices of SORT_CAP entries) before the scan starts.
+// The workgroup's LDS — this + the 8 KiB staging buffer + a few words — stays under 32 KiB: five workgroups per CU.
+constexpr uint32_t PHASE_C_BYTES = LDS_C_OFF + (SORT_CAP * 8 > 4 * WAVE_C_BYTES ? SORT_CAP * 8 : 4 * WAVE_C_BYTES);
 constexpr uint32_t REC_COMMON = 0x80000000u;  // in a lane's winning record index: the key's common-case bit (record indices stay below 2^31)
 
 // The lane's pixel (rx, ry) in the tile and its word li in the tile's LDS images, made afresh from the thread index
@@ -1207,11 +1240,8 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
     unsigned char* mine = s_c + LDS_C_OFF + wv * WAVE_C_BYTES;
     enc_t* col = lc + (uint32_t)(row0 + ((int)wv << lrpw)) * TILE;  // this wave's rows of the colour tile
     uint2* q = reinterpret_cast<uint2*>(mine);
-    unsigned long long* mask = reinterpret_cast<unsigned long long*>(mine + QUEUE_CAP * 8);
-    float4* s_src = reinterpret_cast<float4*>(mine + QUEUE_CAP * 8 + 256 * 8);
-    for (uint32_t i = tid_of(wv) & 63u; i < 256u; i += 64u) mask[i] = 0ull;
-    // (the first barrier inside the scan orders these writes)
-    scan_columns_ordered<FMT, INSTR>(P, s_cov, s_idx, order, n_list, tx0, ty0, row0, lrpw, s_z, col, q, mask, s_src, n_raster, n_shaded, wv);
+    float4* s_src = reinterpret_cast<float4*>(mine + QUEUE_CAP * 8);
+    scan_columns_ordered<FMT, INSTR>(P, s_cov, s_idx, order, n_list, tx0, ty0, row0, lrpw, s_z, col, q, s_src, n_raster, n_shaded, wv);
 #pragma unroll
     for (int k = 0; k < 4; k++) dirty[k] = pix_ok[k];
     }
@@ -1271,7 +1301,7 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
 // quarter path merely compiled in costs the whole-tile path 2-3 % (registers, code size), which a pass with
 // more than SPLIT_TILES_MAX tiles — where no tile is worth splitting — need not pay.
 #ifndef SVR_TILE_WAVES
-#define SVR_TILE_WAVES 4  // workgroups per CU the tile kernel is compiled for (A/B builds: tools/build_variant.sh)
+#define SVR_TILE_WAVES 5  // waves per SIMD (= workgroups per CU) the tile kernel is compiled for (A/B builds: tools/build_variant.sh)
 #endif
 template <int FMT, bool INSTR, bool SPLIT>
 __global__ __launch_bounds__(256, SVR_TILE_WAVES) void tile_kernel(FrameParams P) {
@@ -1279,7 +1309,9 @@ __global__ __launch_bounds__(256, SVR_TILE_WAVES) void tile_kernel(FrameParams P
   __shared__ uint32_t s_idx[BATCH];
   __shared__ __attribute__((aligned(16))) unsigned char s_c[PHASE_C_BYTES];  // phase A depth tile, phase C blocks
   static_assert(LDS_Z_OFF + QUARTER_LIST_CAP * 4 <= PHASE_C_BYTES, "depth tile + a quarter's triangle list");
-  static_assert(SPLIT_SORT_MAX <= SORT_CAP && 4 * WAVE_C_BYTES >= SORT_CAP * 8 && 4 * WAVE_C_BYTES >= RANK_SORT_MAX * 8, "sort scratch aliases the waves' phase-C blocks");
+  static_assert(SPLIT_SORT_MAX <= SORT_CAP && PHASE_C_BYTES - LDS_C_OFF >= SORT_CAP * 8 && PHASE_C_BYTES - LDS_C_OFF >= RANK_SORT_MAX * 8 &&
+                    PHASE_C_BYTES - LDS_C_OFF >= 4 * WAVE_C_BYTES, "sort scratch aliases the waves' phase-C blocks");
+  static_assert(sizeof(s_cov) + sizeof(s_idx) + PHASE_C_BYTES + 64 <= 32768, "five workgroups per CU: 160 KiB of LDS");
   static_assert(TILE * TILE * 8 >= TILE * TILE * sizeof(uint2), "the colour tile aliases the visibility tile");
 
   // Everything the workgroup needs before it can start comes in ONE round of scalar loads: the failure flags

@@ -528,7 +528,6 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   const bool all_stages = ctx->kernel_timing >= 2;
   if (ts >= 0 && all_stages) HIPCHK(hipEventRecord(ctx->tev[ts][0], g));
   launch_setup(P, g);
-  launch_clip(P, g);
   if (ts >= 0 && all_stages) HIPCHK(hipEventRecord(ctx->tev[ts][1], g));
   launch_bin_count(P, g);
   launch_bin_scan(P, g);
@@ -621,7 +620,7 @@ int recover_from_overflow(SvrContext* ctx) {
       if (c.overflow & 1u) ctx->clip_cap = std::max<uint32_t>(ctx->clip_cap * 2u, c.n_clip + 1024u);
       if (c.overflow & 2u) ctx->extra_cap = std::max<uint32_t>(ctx->extra_cap * 2u, c.n_extra + 1024u);
       if (c.overflow & 4u) {
-        uint32_t need = std::max(c.total_entries, c.n_pairs);
+        uint32_t need = std::max(c.total_entries, c.n_pairs + c.n_pairs_rest);
         ctx->bin_cap = std::max<uint32_t>(ctx->bin_cap * 2u, need + need / 4u);
       }
       HIPCHK(hipMemsetAsync(ctx->d_poison, 0, sizeof(uint32_t), ctx->stream));

@@ -49,7 +49,7 @@ constexpr uint32_t SPLIT_TILES_MAX = 4096;     // passes over more tiles run the
 constexpr uint32_t ROW_COST_MAX = 512;        // tile rows of the largest target (16384 / 32)
 constexpr uint32_t TILE_SLOTS = 1024;          // 256 CUs x 4 resident tile workgroups
 __host__ __device__ inline uint32_t tile_cost(uint32_t n_op, uint32_t n_tr) { return 40u + (n_op >> 3) + n_tr - (n_tr >> 2); }
-constexpr uint32_t SPLIT_SORT_MAX = 2048;      // quarters sort in LDS, out of place (k_tile.hip SORT_CAP): larger transparent bins stay whole
+constexpr uint32_t SPLIT_SORT_MAX = 1408;      // quarters sort in LDS, out of place (k_tile.hip SORT_CAP): larger transparent bins stay whole
 
 // One draw call (RenderObject after cull+sort), 192 bytes.  Read by the setup kernel through scalar loads
 // (the draw is wave-uniform): the whole record arrives in one round trip.
@@ -145,8 +145,8 @@ struct Counters {
   unsigned long long shaded;
   unsigned long long binned;
   uint32_t n_big;          // triangles over 16 tiles queued by the setup kernel (binned wave-per-record)
-  uint32_t n_pairs;        // (bin, record) pairs appended so far (keeps counting past pair capacity)
-  uint32_t n_pairs_setup;  // n_pairs when the setup kernel had finished (snapshot taken by clip_kernel)
+  uint32_t n_pairs;        // (bin, record) pairs the setup kernel appended (keeps counting past pair capacity)
+  uint32_t n_pairs_rest;   // pairs the count launch appends itself (big triangles, clipper pieces), from the list's END downwards
   uint32_t sort_used;      // words of the sort arena handed out to transparent bins too large for an LDS sort
   uint32_t n_split;        // tiles fill_kernel cut into quarters (keeps counting past SPLIT_MAX)
   uint32_t cost_sum;       // sum of tile_cost over the pass's tiles (offsets_kernel)

@@ -10,7 +10,6 @@ namespace svr {
 void launch_prologue(const void* host_src, void* dst, size_t copy_bytes, void* zero, size_t zero_bytes, uint32_t n_draws,
                      const SvrSceneData& scene, hipStream_t s);
 void launch_setup(const FrameParams& P, hipStream_t s);
-void launch_clip(const FrameParams& P, hipStream_t s);
 void launch_mesh_vert(const SvrVertex* vtx, uint32_t first, uint32_t n, const float* world16,
                       const float* viewproj16, const float* color_factors4, float* out_clip,
                       float* out_varyings, hipStream_t s);

@@ -190,7 +190,7 @@ class ShardedFrame:
     """One frame slot: full-frame colour/depth tensors, this rank's band, and the scissor that makes the
     renderer fill exactly that band.  plan=None: the fixed equal bands of round 1."""
 
-    def __init__(self, torch, renderer, rank, world, device, color_format, bind=True, present=True, plan=None):
+    def __init__(self, torch, renderer, rank, world, device, color_format, bind=True, present=True, plan=None, verify="frame"):
         from . import abi
         self.torch, self.r, self.rank, self.world = torch, renderer, rank, world
         self.W, self.H = renderer.width, renderer.height
@@ -221,6 +221,15 @@ class ShardedFrame:
         self.side = torch.cuda.Stream(device=device) if self.on_gpu else None
         self.status_ready = torch.cuda.Event() if self.on_gpu else None
         self.exchanged_again = 0  # frames this slot had to exchange a second time
+        # verify = "frame": every exchange carries the ranks' status words and every slot is checked before it is reused
+        # or handed out (what libsvr_dist.so does, where the second collective costs a few microseconds of enqueue).
+        # verify = "fence": nothing per frame — from Python a second collective and its host copy cost 20-30 us against
+        # 60-us frames; finish() (a fence) then compares the renderer's replayed_passes with the last fence's, all-reduces
+        # the verdict and presents + exchanges the slot again.  Frames between a void pass and the next fence may have
+        # carried stale rows: for callers that hand out frames only at fences (bench.py).
+        assert verify in ("frame", "fence")
+        self.verify = verify
+        self._replays = 0  # verify = "fence": the renderer's replayed_passes as of the last finish()
 
     def begin(self):
         """Make this slot the render target; waits (on the stream) for the slot's previous exchange."""
@@ -232,13 +241,19 @@ class ShardedFrame:
             self.r.bind_targets(self.color.data_ptr(), self.depth.data_ptr())
         if self.partition == "interleaved":
             self.y0, self.rows = 0, sum(n for _, n in interleaved_rows(self.H, self.rank, self.world))
-            self.r.set_scissor(0, 0, self.W, self.H)
-            self.r.set_row_interleave(self.world, self.rank)
+            self._rows_state((0, 0, self.W, self.H), (self.world, self.rank))
             return
         self.y0, self.rows = self.bounds[self.rank], self.bounds[self.rank + 1] - self.bounds[self.rank]
-        self.r.set_row_interleave(1, 0)
-        if self.rows > 0:
-            self.r.set_scissor(0, self.y0, self.W, self.rows)
+        self._rows_state((0, self.y0, self.W, self.rows) if self.rows > 0 else None, (1, 0))
+
+    def _rows_state(self, scissor, interleave):
+        """scissor + row interleave of the renderer, set only when they change (every call is host time of a frame)"""
+        last = getattr(self.r, "_sharded_rows", (None, None))
+        if interleave != last[1]:
+            self.r.set_row_interleave(*interleave)
+        if scissor is not None and scissor != last[0]:
+            self.r.set_scissor(*scissor)
+        self.r._sharded_rows = (scissor if scissor is not None else last[0], interleave)
 
     def _wait(self):
         if self.work is not None:
@@ -249,7 +264,7 @@ class ShardedFrame:
     def _exchange(self, dist, async_op):
         """every rank's rows -> every rank's frame, in place; every rank's status word behind them"""
         works = self._exchange_rows(dist, async_op)
-        if self.present:
+        if self.present and self.verify == "frame":
             h = dist.all_gather_into_tensor(self.status, self.status[self.rank:self.rank + 1], async_op=async_op)
             if async_op:
                 works = (works if isinstance(works, list) else ([works] if works is not None else [])) + [h]
@@ -321,9 +336,11 @@ class ShardedFrame:
         """Exchange the finished bands; in place (a rank's band is its rows of the full frame)."""
         if self.present:
             if self.rows > 0:  # vkutil::copy_image of this rank's rows (scissor / row set are still the frame's)
-                self.r.set_present_status(self.status[self.rank:].data_ptr())
+                if self.verify == "frame":
+                    self.r.set_present_status(self.status[self.rank:].data_ptr())
                 self.r.copy_to_swapchain(self.swapchain.data_ptr(), self.W, self.H, 0)
-                self.r.set_present_status(0)
+                if self.verify == "frame":
+                    self.r.set_present_status(0)
         elif not self.bound:  # test path (CPU oracle owns its targets): copy the band out first
             col = self.r.read_color()
             t = self.torch.from_numpy(col.view(np.float16) if col.dtype == np.uint16 else col)
@@ -339,7 +356,7 @@ class ShardedFrame:
         """The frame this slot last exchanged, made final: if any rank's present of it was void (1) or rerun by the
         replay, possibly under the exchange (2), fence the renderer — the owner's replay runs there — and exchange the
         slot again.  Collective without a message of its own: every rank reads the same gathered words."""
-        if self.world == 1 or not self.present or self._dist is None:
+        if self.world == 1 or not self.present or self._dist is None or self.verify != "frame":
             return
         for attempt in range(5):
             if self.on_gpu:
@@ -361,6 +378,24 @@ class ShardedFrame:
         """Wait for the slot's exchange and make its frame final (see _repair)."""
         self._wait()
         self._repair()
+        if self.verify == "fence" and self.world > 1 and self.bound and self._dist is not None:
+            try:
+                now = int(self.r.get_stats().replayed_passes)  # fences the renderer: a replay that was due has run
+            except AttributeError:  # the CPU oracle (tests) has no queues to overflow
+                now = 0
+            flag = self.torch.tensor([1 if now != self._replays else 0], dtype=self.torch.int32, device=self.color.device)
+            self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX)  # the re-send is a collective: all ranks or none
+            self._replays = now
+            if int(flag.item()):
+                if self.present and self.rows > 0:  # the replayed rows: presented again (the replay's own present may have
+                    self.r.bind_targets(self.color.data_ptr(), self.depth.data_ptr())  # gone to the other slot's image)
+                    self.r._sharded_rows = (None, None)
+                    self._rows_state((0, 0, self.W, self.H) if self.partition == "interleaved" else (0, self.y0, self.W, self.rows),
+                                     (self.world, self.rank) if self.partition == "interleaved" else (1, 0))
+                    self.r.copy_to_swapchain(self.swapchain.data_ptr(), self.W, self.H, 0)
+                    self.r.sync()
+                self._exchange(self._dist, False)
+                self.exchanged_again += 1
 
     def image(self):
         """The gathered frame without the padding rows (B8G8R8A8 swapchain bytes, or the colour target)."""

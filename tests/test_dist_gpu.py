@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, width, height, out_dir, partition="bands", queue_caps=None):
+def _worker(rank, world, port, width, height, out_dir, partition="bands", queue_caps=None, verify="frame"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -42,7 +42,7 @@ def _worker(rank, world, port, width, height, out_dir, partition="bands", queue_
         if queue_caps is not None:
             r.set_option(P.abi.OPT_QUEUE_CAPS, queue_caps)  # the first passes overflow, are void, and replayed later
             r.set_option(P.abi.OPT_TUNING, 16)              # ... found at a fence, not in passing: the present behind them is void
-        slots = [P.dist.ShardedFrame(torch, r, rank, world, dev, P.abi.COLOR_RGBA16F, plan=plan) for _ in range(2)]
+        slots = [P.dist.ShardedFrame(torch, r, rank, world, dev, P.abi.COLOR_RGBA16F, plan=plan, verify=verify) for _ in range(2)]
         for f in range(5):  # five frames through two slots, nothing fenced in between
             s = slots[f % 2]
             s.begin()
@@ -101,14 +101,15 @@ def test_interleaved_tile_rows_present_and_gather(tmp_path, hip, world, size):
         assert np.array_equal(np.load(tmp_path / f"rank{rank}.npy"), ref), f"rank {rank} of {world}"
 
 
-@pytest.mark.parametrize("partition", ["bands", "interleaved"])
-def test_a_replayed_pass_is_exchanged_again(tmp_path, hip, partition):
+@pytest.mark.parametrize("partition,verify", [("bands", "frame"), ("interleaved", "frame"), ("bands", "fence")])
+def test_a_replayed_pass_is_exchanged_again(tmp_path, hip, partition, verify):
     """queues start tiny: the first passes overflow, their presents are void and say so in the status words that travel
-    behind the rows; every rank then fences and exchanges the slot again before it reuses it (dist.py _repair)"""
+    behind the rows; every rank then fences and exchanges the slot again before it reuses it (dist.py _repair).
+    verify = "fence": nothing travels per frame; finish() compares replayed_passes and repairs collectively"""
     torch = pytest.importorskip("torch")
     import torch.multiprocessing as mp
     w, h = 192, 108
-    mp.spawn(_worker, args=(2, _free_port(), w, h, str(tmp_path), partition, 16), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), w, h, str(tmp_path), partition, 16, verify), nprocs=2, join=True)
     ref = _reference(hip, w, h)
     again = [np.load(tmp_path / f"again{rank}.npy") for rank in range(2)]
     for rank in range(2):
