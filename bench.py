@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--min-gain", type=float, default=0.2, help="N > 1: a cost-balanced cut replaces the equal bands only if it shortens the heaviest band by this fraction (unequal bands cost the host a batch of send/recv per frame instead of one all-gather)")
     ap.add_argument("--rebalance", type=int, default=64, help="N > 1: frames between two re-cuts of the row bands (0 = never)")
     ap.add_argument("--gather-fp16", action="store_true", help="N > 1: all-gather the RGBA16F target instead of the swapchain image")
+    ap.add_argument("--partition", default="auto", choices=["auto", "bands", "interleaved"],
+                    help="N > 1: contiguous row bands, interleaved tile rows (t %% N == rank), or whichever a short trial of both finds faster")
     ap.add_argument("--cpu-frames", type=int, default=10)
     ap.add_argument("--blocks", type=int, default=25, help="repetitions of the timed --steps block (the median block is reported)")
     ap.add_argument("--profile-tag", default="r02_i", help="profiles/<tag>_traffic.json and <tag>_valu.json of this build are quoted in the line")
@@ -231,6 +233,26 @@ def main():
         frame()
     fence()
     note(f"warm-up done, rows {plan.bounds}")
+    if world > 1 and args.partition != "bands":
+        if args.partition == "interleaved":
+            plan.partition = "interleaved"
+        else:  # a short trial of either partition (wall clock of a few blocks of frames, fenced), then the collective pick
+            def trial(name):
+                plan.partition = name
+                for _ in range(max(args.warmup, 4)):
+                    frame()
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(4 * args.steps):
+                    frame()
+                fence()
+                return (time.perf_counter() - t0) / (4 * args.steps) * 1e3
+            tb, ti = trial("bands"), trial("interleaved")
+            picked = plan.pick(torch, dist, dev, tb, ti)
+            note(f"partition trial: bands {tb:.4f} ms, interleaved {ti:.4f} ms per frame on rank 0 -> {picked}")
+        for _ in range(args.warmup):
+            frame()
+        fence()
     r.set_option(A.OPT_KERNEL_TIMING, 1)
 
     def block():
@@ -298,7 +320,8 @@ def main():
                        "width": W, "height": H, "triangles": counts_scene["triangles"] * args.instances,
                        "draws": int(len(opaque) + len(transparent)),
                        "textures": f"{len(sc.textures)} images from the file" if args.gltf else f"25 x {args.tex_size}^2 RGBA8 mipmapped",
-                       "parallelism": (f"row bands x{world} ({'equal' if args.equal_bands else 'cost-balanced, rows ' + str(plan.bounds)}) + exchange of the "
+                       "parallelism": ((f"interleaved tile rows (t % {world} == rank), in-place all-gathers per {world} tile rows" if plan.partition == "interleaved" else
+                                        f"row bands x{world} ({'equal' if args.equal_bands else 'cost-balanced, rows ' + str(plan.bounds)})") + f" [--partition {args.partition}] + exchange of the "
                                        + ("B8G8R8A8 swapchain image" if present else "RGBA16F target")) if world > 1 else "single GPU"},
             "frames_per_s": fps,
             "shaded_fragments_per_frame": shaded, "rasterized_fragments_per_frame": rasterized,

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(1024) void prefix_kernel(FlattenParams F) {
     if (first + k < n) {
       uint32_t t = F.draw_tris[first + k];
       tri += t;
-      chk += (t + 63u) >> 6;
+      chk += chunk_count(F.draws[first + k].first_index, t);
     }
   uint32_t itri = tri, ichk = chk;
   for (int off = 1; off < 64; off <<= 1) {
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(1024) void prefix_kernel(FlattenParams F) {
       F.draws[first + k].tri_base = rt;
       F.chunk_base[first + k] = rc;
       rt += t;
-      rc += (t + 63u) >> 6;
+      rc += chunk_count(F.draws[first + k].first_index, t);
     }
   if (tid == 0) {
     F.counters->flat_draws = n;
@@ -169,10 +169,11 @@ __global__ __launch_bounds__(256) void chunks_kernel(FlattenParams F) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= F.counters->flat_draws) return;
   uint32_t t = F.draw_tris[r], base = F.chunk_base[r];
-  for (uint32_t c = 0, first = 0; first < t; c++, first += 64u) {
+  const uint32_t fi = F.draws[r].first_index;
+  for (uint32_t c = 0, nc = chunk_count(fi, t); c < nc; c++) {
     WaveChunk ch;
     ch.draw = r;
-    ch.first_tri = first;
+    ch.first_tri = chunk_first(fi, c);
     F.chunks[base + c] = ch;
   }
 }

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, 4) void setup_kernel(FrameParams P) {
   // vertices comes from the mesh's index-group table (svr_upload_mesh).
   uint32_t v_first = 0, v_count = 0;  // wave-uniform
   if (live && d.groups && kind != PIPE_COLORED_TRIANGLE) {
-    const uint32_t first = d.first_index + 3u * ch.first_tri, last = first + 3u * min(64u, d.tri_count - ch.first_tri) - 1u;
+    const uint32_t first = d.first_index + 3u * ch.first_tri, last = first + 3u * chunk_len(d.first_index, d.tri_count, ch.first_tri) - 1u;
     typedef const __attribute__((address_space(4))) float* const_floats;
     const_floats g0 = (const_floats)(const void*)(d.groups + GROUP_WORDS * (first / GROUP_INDICES));
     const_floats g1 = (const_floats)(const void*)(d.groups + GROUP_WORDS * (last / GROUP_INDICES));
@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256, 4) void setup_kernel(FrameParams P) {
     }
     if (boxes_ok) live = chunk_can_be_seen(P, d.mvp, lo, hi, lane);
   }
-  uint32_t tri = live ? ch.first_tri + lane : 0xffffffffu;
+  // (a chunk ends at the next line of the mesh's index-group grid: svr_device.h chunk_len)
+  uint32_t tri = (live && lane < chunk_len(d.first_index, d.tri_count, ch.first_tri)) ? ch.first_tri + lane : 0xffffffffu;
   uint32_t seq = d.tri_base + tri;
   __shared__ uint32_t s_tot[8];
   __shared__ uint4 s_tr[4][64 * 8];  // per wave: one half (8 pieces) of its 64 records, for the transposed store

@@ -488,9 +488,9 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
     WaveChunk* ch = reinterpret_cast<WaveChunk*>((char*)stage + draw_bytes);
     size_t ci = 0;
     for (size_t di = 0; di < draws.size(); di++)
-      for (uint32_t t = 0; t < draws[di].tri_count; t += 64u) {
+      for (uint32_t k = 0, nk = chunk_count(draws[di].first_index, draws[di].tri_count); k < nk; k++) {
         ch[ci].draw = (uint32_t)di;
-        ch[ci].first_tri = t;
+        ch[ci].first_tri = chunk_first(draws[di].first_index, k);
         ci++;
       }
   }
@@ -801,7 +801,7 @@ int run_pass(SvrContext* ctx, const SvrSceneData* scene, std::vector<DrawDesc>& 
   for (DrawDesc& d : draws) {
     d.tri_base = (uint32_t)n_tris64;
     n_tris64 += d.tri_count;
-    n_chunks += (d.tri_count + 63u) / 64u;
+    n_chunks += chunk_count(d.first_index, d.tri_count);
   }
   FrameParams P;
   const SvrContext::PendingClear asked = ctx->pending_clear;  // folded into P.lazy_clear below: put back if the pass is not enqueued
@@ -1390,7 +1390,7 @@ int svr_draw_geometry(SvrContext* ctx, const SvrSceneData* scene, const SvrRende
     for (size_t i = 0; i < n_objects; i++) {
       uint32_t t = (i < n_opaque ? opaque[i] : transparent[i - n_opaque]).index_count / 3u;
       tris_max += t;
-      chunks_max += (t + 63u) / 64u;
+      chunks_max += chunk_count((i < n_opaque ? opaque[i] : transparent[i - n_opaque]).first_index, t);
     }
     SvrStats st{};
     int e = run_pass_flatten(ctx, scene, opaque, n_opaque, transparent, n_transparent, tris_max, chunks_max);

@@ -70,6 +70,20 @@ struct DrawDesc {
 };
 static_assert(sizeof(DrawDesc) == 192 && offsetof(DrawDesc, vtx) == 144 && offsetof(DrawDesc, groups) == 176, "DrawDesc layout");
 constexpr uint32_t GROUP_INDICES = 192;  // 64 triangles
+// A draw's triangles are cut into wave chunks ALONG the grid of its mesh's index groups (triangle number
+// first_index / 3 + t, in steps of 64), not from the draw's first triangle on: a chunk then lies inside ONE group — one box
+// to cull it with, one short run of the vertex buffer to shade (chunks that straddled two groups were culled by the union
+// of two boxes and shaded the union of two runs, often past the 128 vertices the staging holds).  The first and last
+// chunk of a draw may be short.  A draw whose first index is not a multiple of 3 keeps the plain cut (phase 0).
+__host__ __device__ inline uint32_t chunk_phase(uint32_t first_index) { return first_index % 3u == 0u ? (first_index / 3u) & 63u : 0u; }
+__host__ __device__ inline uint32_t chunk_count(uint32_t first_index, uint32_t tri_count) {
+  return tri_count ? (chunk_phase(first_index) + tri_count + 63u) / 64u : 0u;
+}
+__host__ __device__ inline uint32_t chunk_first(uint32_t first_index, uint32_t k) { return k ? 64u * k - chunk_phase(first_index) : 0u; }
+__host__ __device__ inline uint32_t chunk_len(uint32_t first_index, uint32_t tri_count, uint32_t first_tri) {
+  const uint32_t to_grid = 64u - ((chunk_phase(first_index) + first_tri) & 63u), left = tri_count - first_tri;
+  return to_grid < left ? to_grid : left;
+}
 constexpr uint32_t GROUP_WORDS = 8;      // a group's entry: float[6] box of the vertices its indices name, then their lowest and highest vertex index (uint32)
 
 // 64 consecutive triangles of one draw: the unit of work of one wave of the setup kernel.

@@ -116,3 +116,54 @@ def test_a_replayed_pass_is_exchanged_again(tmp_path, hip, partition, verify):
         assert np.array_equal(np.load(tmp_path / f"rank{rank}.npy"), ref), f"rank {rank}"
     assert again[0][0] == again[1][0] >= 1, again          # the repair is collective
     assert max(a[1] for a in again) >= 1, again            # and there was something to repair
+
+
+def _nccl_single(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        sys.path.insert(0, os.path.join(g.ROOT, "tests"))
+        P = g.load_package()
+        hip = P.load_product_library()
+        w, h = 192, 108
+        r, scene, opaque, transparent = T.setup_sponza(hip, w, h, lod=8, tex_size=32)
+        r.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        r.clear_color((1, 1, 1, 1))
+        r.draw_geometry(scene, opaque, transparent)
+        ref = r.read_swapchain(w, h, P.abi.SWAPCHAIN_B8G8R8A8)
+        for partition in ("bands", "interleaved"):
+            plan = P.dist.BandPlan(h, 1, balanced=False)
+            plan.partition = partition
+            s = P.dist.ShardedFrame(torch, r, 0, 1, dev, P.abi.COLOR_RGBA16F, plan=plan)
+            for _ in range(3):
+                s.begin()
+                r.clear_color((1, 1, 1, 1))
+                r.draw_geometry(scene, opaque, transparent)
+                s.gather(dist)                 # world 1: presents, no exchange ...
+                s._dist = dist
+                s.work = s._exchange(dist, True)  # ... so the exchange is called by hand: the RCCL code path, one rank
+                s.finish()
+            torch.cuda.synchronize(dev)
+            assert np.array_equal(s.image().cpu().numpy(), ref), partition
+            assert s.h_status.tolist() == [0]
+            assert plan.pick(torch, dist, dev, 2.0, 1.0) == "interleaved" and plan.pick(torch, dist, dev, 1.0, 2.0) == "bands"
+        r.close()
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_the_rccl_code_path_with_one_rank(tmp_path, hip):
+    """torch.distributed backend "nccl" (= RCCL) refuses two ranks on one device, so the calls bench.py --gpus N makes —
+    the in-place all_gather_into_tensor of equal bands, the coalesced group of per-tile-row-group all-gathers of the
+    interleaved partition, the status words' all-gather and its side-stream copy, the pick's all-reduce — run here with
+    a world of one: the API use is exercised on hardware even though no peer exists"""
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    mp.spawn(_nccl_single, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "ok").exists()
