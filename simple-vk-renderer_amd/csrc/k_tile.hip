@@ -8,8 +8,8 @@
 // (src/vk_initializers.cpp:117-164).
 //
 // One 256-thread workgroup per 32x32 tile, launched heaviest tile first.  Pixel ownership: wave w owns
-// the 16x16 quadrant w and lane l four pixels of it (one per 8x8 block); from the end of phase A to the
-// final store their depth, key, record and colour live in VGPRs.
+// the 16x16 quadrant w and lane l four pixels of it (one per 8x8 block); from the end of phase A a lane holds its four
+// winning record indices, the tile's depth and colour live in LDS.
 //   phase A  opaque visibility by column scan: the bin is staged through LDS 64 records at a time, every
 //            triangle expands into one work item per pixel column of its bbox, a lane walks its column
 //            with exact fp64 edge increments and resolves visibility with ds_max_u64 on an LDS
@@ -18,13 +18,14 @@
 //   phase B  shade each visible pixel once (deferred: identical result, no overdraw shading); a
 //            specialised instance serves waves whose pixels all carry the key's common-case bit
 //   phase C  transparent bin sorted by key in LDS, banded column scan (wave w owns rows 8w..8w+7) that
-//            appends depth-passing fragments to per-wave queues in submission order, shaded 64 at a
-//            time, blended at target precision; bins over SORT_CAP (1408) entries sort in a global arena instead
+//            appends depth-passing fragments to per-wave queues in submission order; the scan stops whenever a
+//            queue holds 64 fragments, they are shaded and blended at target precision, and the scan resumes from a
+//            (chunk, row) pair; bins over SORT_CAP (1408) entries sort in a global arena instead
 //   phase D  write-back: whole tiles go out through LDS as full rows, the depth CLEAR and a deferred
 //            svr_clear_color are fused here
 // Heavy tiles of small passes are rendered as four 8-row quarters by four workgroups (tile_kernel<.., SPLIT>).
-// What bounds it is VALU issue (the fragment stage is ~400-460 instructions per pixel), not HBM:
-// DESIGN.md "Tile kernel".  128 VGPRs = 4 workgroups per CU.
+// What bounds it is memory latency and VALU issue (the fragment stage is ~350 instructions per pixel), not HBM:
+// DESIGN.md "Tile kernel".  <= 96 VGPRs and < 32 KiB of LDS = 5 workgroups per CU (round 3; 124 / 37 KiB = 4 before).
 #include <hip/hip_fp16.h>
 
 #include <hip/hip_ext.h>

@@ -28,6 +28,8 @@ json.dump({"kernel": "tile_kernel<RGBA16F, uninstrumented, whole tiles>", "bound
            "active_quad_cycles": vals["SQ_ACTIVE_INST_VALU"], "avg_launch_ns": avg_ns,
            "issue_frac": vals["SQ_ACTIVE_INST_VALU"] / simd_quad_cycles,
            "wave_cycles": vals.get("SQ_WAVE_CYCLES"), "wait_any": vals.get("SQ_WAIT_ANY"), "wait_inst_any": vals.get("SQ_WAIT_INST_ANY"),
+           # resident waves per SIMD, averaged over the kernel: wave-residence quad-cycles against the SIMDs' quad-cycles
+           "mean_waves_per_simd": (vals["SQ_WAVE_CYCLES"] / simd_quad_cycles) if vals.get("SQ_WAVE_CYCLES") else None,
            "definition": "SQ_ACTIVE_INST_VALU (quad-cycles the SIMDs spent issuing VALU) / (1024 SIMDs x the kernel's average duration at 2.4 GHz / 4)",
            "source": f"profiles/{tag}_pmc.txt + profiles/{tag}_kernel_stats.csv"},
           open(f"{out}/{tag}_valu.json", "w"), indent=1)
