@@ -36,6 +36,7 @@
 
 namespace svr {
 
+constexpr uint32_t REC_COMMON = 0x80000000u;  // in a lane's winning record index: the key's common-case bit (record indices stay below 2^31)
 constexpr int BATCH = 64;  // triangles staged per LDS batch == wave size: 64 x 128 B = 8 KiB
 
 // ------------------------------------------------------------------------------------------------
@@ -471,10 +472,15 @@ __device__ __forceinline__ void flush_fragments(const FrameParams& P, typename C
   uint32_t pix = e.x, rec = e.y;  // pix = row in band * 32 + column in tile
   int px = tx0 + (int)(pix & 31u), py = by0 + (int)(pix >> 5);
   float4 src = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (act) {
-    src = shade_pixel<false>(P, rec, px, py, nullptr);
-    if (INSTR) n_shaded++;
+  // the specialised fragment stage (mesh.frag, trilinear sampler, power-of-two image: the key's common-case bit rides
+  // in the queued record index) when every fragment of the group carries it, as in phase B: the curtain tiles' ordered
+  // pass — 36 layers deep, the kernel's slowest tiles — is nine tenths shading
+  if (__all(!act || (rec & REC_COMMON))) {  // wave-uniform
+    if (act) src = shade_pixel<false, true>(P, rec & ~REC_COMMON, px, py, nullptr);
+  } else if (act) {
+    src = shade_pixel<false>(P, rec & ~REC_COMMON, px, py, nullptr);
   }
+  if (INSTR && act) n_shaded++;
   // Blending is ordered per pixel (C13) and a group of 64 queued fragments often holds many layers of
   // the same few pixels (a curtain seen edge-on).  Every pixel's fragments are collected as a lane mask,
   // and the lowest lane of each mask blends its pixel's fragments in lane order = submission order, in
@@ -504,7 +510,7 @@ __device__ __forceinline__ void flush_fragments(const FrameParams& P, typename C
       // enable_blending_additive: rgb = src*ONE + dst*DST_ALPHA, a = src*ONE + dst*ZERO
       float4 o = make_float4(fmaf(dst.x, dst.w, sj.x), fmaf(dst.y, dst.w, sj.y), fmaf(dst.z, dst.w, sj.z), sj.w);
       if (INSTR && P.trace_buf && px == P.trace_x && py == P.trace_y) {
-        (void)shade_pixel<true>(P, q[j].y, px, py, P.trace_buf);
+        (void)shade_pixel<true>(P, q[j].y & ~REC_COMMON, px, py, P.trace_buf);
         float* tb = P.trace_buf;
         tb[32] = dst.x; tb[33] = dst.y; tb[34] = dst.z; tb[35] = dst.w;
         tb[36] = o.x; tb[37] = o.y; tb[38] = o.z; tb[39] = o.w;
@@ -649,7 +655,7 @@ __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4
           g1 += B1;
           g2 += B2;
           if (m) {
-            if (pass) q[qn + (uint32_t)__popcll(m & below)] = make_uint2((uint32_t)(t * TILE + colx), ri);
+            if (pass) q[qn + (uint32_t)__popcll(m & below)] = make_uint2((uint32_t)(t * TILE + colx), ri | ((h.z & 2u) ? REC_COMMON : 0u));
             qn += (uint32_t)__popcll(m);
             if (qn >= 64u) {  // stop here: the group is shaded with none of the above alive
               full = true;
@@ -986,7 +992,6 @@ constexpr uint32_t WAVE_C_BYTES = QUEUE_CAP * 8 + 64 * 16;  // queue | shaded co
 // the four waves' blocks, or the sort's scratch (keys + record indices of SORT_CAP entries) before the scan starts.
 // The workgroup's LDS — this + the 8 KiB staging buffer + a few words — stays under 32 KiB: five workgroups per CU.
 constexpr uint32_t PHASE_C_BYTES = LDS_C_OFF + (SORT_CAP * 8 > 4 * WAVE_C_BYTES ? SORT_CAP * 8 : 4 * WAVE_C_BYTES);
-constexpr uint32_t REC_COMMON = 0x80000000u;  // in a lane's winning record index: the key's common-case bit (record indices stay below 2^31)
 
 // The lane's pixel (rx, ry) in the tile and its word li in the tile's LDS images, made afresh from the thread index
 // where a later phase needs them.  Kept in registers from the top of the kernel they are the two values the allocator

@@ -772,7 +772,9 @@ int fill_frame_params(SvrContext* ctx, const SvrSceneData* scene, uint64_t n_tri
   P.trace_y = ctx->trace_y;
   P.trace_buf = (ctx->instrument && ctx->trace_x >= 0) ? (float*)ctx->d_trace.p : nullptr;
   P.tuning = ctx->tuning;
+#ifndef SVR_AB_SPLIT_ALL  // A/B builds only (tools/build_variant.sh): the quarter path for passes of any size
   if (P.n_tiles > SPLIT_TILES_MAX) P.tuning |= TUNE_NO_SPLIT;  // svr_device.h: no tile of such a pass is worth splitting
+#endif
   P.tile_cycles = nullptr;
   if (ctx->tile_cycles) {
     if (int e = ctx->d_tile_cycles.ensure((size_t)P.n_tiles * 16)) return e;

@@ -47,7 +47,10 @@ constexpr uint32_t SPLIT_EXTRA = 4 * SPLIT_MAX;
 constexpr uint32_t SPLIT_MIN_COST = 100;
 constexpr uint32_t SPLIT_TILES_MAX = 4096;     // passes over more tiles run the tile kernel built without the quarter path
 constexpr uint32_t ROW_COST_MAX = 512;        // tile rows of the largest target (16384 / 32)
-constexpr uint32_t TILE_SLOTS = 1024;          // 256 CUs x 4 resident tile workgroups
+#ifndef SVR_AB_TILE_SLOTS  // A/B builds only (tools/build_variant.sh)
+#define SVR_AB_TILE_SLOTS 1024
+#endif
+constexpr uint32_t TILE_SLOTS = SVR_AB_TILE_SLOTS;  // resident tile workgroups the split rule's mean load is taken over
 __host__ __device__ inline uint32_t tile_cost(uint32_t n_op, uint32_t n_tr) { return 40u + (n_op >> 3) + n_tr - (n_tr >> 2); }
 constexpr uint32_t SPLIT_SORT_MAX = 1408;      // quarters sort in LDS, out of place (k_tile.hip SORT_CAP): larger transparent bins stay whole
 

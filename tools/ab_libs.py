@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--stages", action="store_true")
     ap.add_argument("--stream", action="store_true", help="render on a stream of its own (torch.cuda.Stream) instead of the null stream")
     ap.add_argument("--band", default="", help="y0,rows: render only these rows (scissor), as one rank of a sharded frame does")
+    ap.add_argument("--interleave", default="", help="stride,offset: render only the tile rows t with t %% stride == offset (svr_set_row_interleave)")
     args = ap.parse_args()
     pkg = g.load_package()
     import torch  # noqa: F401  (one HIP runtime per process: torch's is loaded first)
@@ -51,6 +52,9 @@ def main():
         if args.band:
             y0, rows = (int(v) for v in args.band.split(","))
             r.set_scissor(0, y0, args.width, rows)
+        if args.interleave:
+            stride, offset = (int(v) for v in args.interleave.split(","))
+            r.set_row_interleave(stride, offset)
         ctx.append((spec, r, opaque, transparent))
     res = {i: [] for i in range(len(ctx))}
     for rnd in range(args.rounds + 1):
