@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--wgtimes", action="store_true", help="with a -DSVR_DEBUG_WG_TIMES build (--lib): where the tile kernel's time goes between workgroups")
     ap.add_argument("--hist", action="store_true")
+    ap.add_argument("--slots", type=int, default=5, help="--wgtimes: tile workgroups a CU holds (5 since round 3, 4 before)")
     ap.add_argument("--flatten", type=int, default=0, help="SVR_OPT_DEVICE_FLATTEN: 0 auto, 1 device, 2 host")
     ap.add_argument("--timing", type=int, default=2, help="SVR_OPT_KERNEL_TIMING during the frames (2 = events around every stage, perturbs the pipeline; 0 for traces)")
     ap.add_argument("--tuning", type=int, default=0, help="SVR_OPT_TUNING mask (2 = stages serialised)")
@@ -107,7 +108,7 @@ def main():
         busy = (end - start).sum()
         ncu = len(np.unique(cu))
         print(f"  tile kernel by workgroup: {start.size} workgroups on {ncu} CUs; first start .. last end {span:.1f} us; "
-              f"sum of residence {busy / 1e3:.1f} ms = {busy / (4 * ncu):.1f} us per slot at 4 per CU")
+              f"sum of residence {busy / 1e3:.1f} ms = {busy / (args.slots * ncu):.1f} us per slot at {args.slots} per CU")
         # resident workgroups per CU over time
         grid = np.arange(0.0, span, 1.0)
         resident = np.zeros(grid.size)
@@ -116,10 +117,12 @@ def main():
         resident /= ncu
         marks = [int(x) for x in np.linspace(0, grid.size - 1, 24)]
         print("  mean resident workgroups per CU at", [f"{grid[m]:.0f}us:{resident[m]:.2f}" for m in marks])
-        full = np.nonzero(resident > 3.9)[0]
+        S = float(args.slots)
+        full = np.nonzero(resident > S - 0.1)[0]
         if full.size:
-            print(f"  chip full (>3.9 per CU) from {grid[full[0]]:.0f} to {grid[full[-1]]:.0f} us; lost slot-time before {np.sum(4 - resident[:full[0]]) / 4:.1f} us-equivalents, "
-                  f"after {np.sum(4 - resident[full[-1]:]) / 4:.1f}, in between {np.sum(4 - resident[full[0]:full[-1]]) / 4:.1f}")
+            print(f"  chip full (>{S - 0.1:.1f} per CU) from {grid[full[0]]:.0f} to {grid[full[-1]]:.0f} us; lost slot-time before {np.sum(S - resident[:full[0]]) / S:.1f} us-equivalents, "
+                  f"after {np.sum(S - resident[full[-1]:]) / S:.1f}, in between {np.sum(S - resident[full[0]:full[-1]]) / S:.1f}")
+        print(f"  time-average of resident workgroups per CU: {resident.mean():.2f} of {args.slots}")
         # hand-over on a CU: from a workgroup's end to the next start on that CU (greedy matching in time order)
         gaps = []
         for c in np.unique(cu):
@@ -134,7 +137,7 @@ def main():
         gaps = np.array(gaps)
         if gaps.size:
             print(f"  hand-over of a CU slot (a workgroup ends -> the next starts there): {gaps.size} hand-overs, median {np.median(gaps):.2f} us, "
-                  f"mean {gaps.mean():.2f}, p90 {np.percentile(gaps, 90):.2f}, sum {gaps.sum() / 1e3:.2f} ms = {gaps.sum() / (4 * ncu):.1f} us per slot")
+                  f"mean {gaps.mean():.2f}, p90 {np.percentile(gaps, 90):.2f}, sum {gaps.sum() / 1e3:.2f} ms = {gaps.sum() / (args.slots * ncu):.1f} us per slot")
         dur = end - start
         print(f"  workgroup residence: median {np.median(dur):.1f} us, p90 {np.percentile(dur, 90):.1f}, max {dur.max():.1f}; the last 5 % of workgroups start after "
               f"{np.percentile(start, 95):.0f} us")
