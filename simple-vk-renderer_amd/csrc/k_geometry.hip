@@ -124,7 +124,12 @@ __global__ __launch_bounds__(256, 4) void setup_kernel(FrameParams P) {
   uint32_t tri = (live && lane < chunk_len(d.first_index, d.tri_count, ch.first_tri)) ? ch.first_tri + lane : 0xffffffffu;
   uint32_t seq = d.tri_base + tri;
   __shared__ uint32_t s_tot[8];
-  __shared__ uint4 s_tr[4][64 * 8];  // per wave: one half (8 pieces) of its 64 records, for the transposed store
+  // per wave 6 KiB: the chunk's shaded vertices (128 x 48 B), then — 4 KiB of it — one half (8 pieces) of 32 of its 64
+  // records at a time, for the transposed store.  24 KiB per workgroup = 20 of gfx950's 1280-byte LDS granules: the
+  // workgroup fits the hole ONE retiring tile workgroup leaves (25 granules; LDS is handed out in contiguous ranges).  With
+  // 8 KiB per wave (the 64 records' half at once) it needed 26 — and once the tile kernel really held five workgroups
+  // per CU, stage 1 of the next frame starved beside it: geometry 0.03 -> 0.13 ms under overlap, every frame longer.
+  __shared__ uint4 s_tr[4][64 * 6];
   // The chunk's vertices through LDS.  Its 192 indices name a short run of the vertex buffer (a mesh's triangles
   // are laid out near their vertices), known from the group table before a single index has arrived: the wave reads
   // that run as it lies — consecutive lanes consecutive 48-byte vertices, 3 KiB per instruction, in flight TOGETHER
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256, 4) void setup_kernel(FrameParams P) {
   // three corners of 64 triangles were three), and parks the results in the wave's (still idle) transposition
   // buffer, where the triangles pick their corners up.  A chunk whose run is longer than STAGE_VERTS gathers as before.
   constexpr uint32_t STAGE_VERTS = 128;
-  static_assert(STAGE_VERTS * sizeof(VOut) <= 64 * 8 * sizeof(uint4), "staged vertices fit the wave's transposition buffer");
+  static_assert(STAGE_VERTS * sizeof(VOut) <= 64 * 6 * sizeof(uint4), "staged vertices fit the wave's buffer");
   const uint32_t wave_in_group = threadIdx.x >> 6;
   VOut* s_v = reinterpret_cast<VOut*>(s_tr[wave_in_group]);
   const bool staged = live && v_count != 0u && v_count <= STAGE_VERTS && kind != PIPE_COLORED_TRIANGLE;  // wave-uniform
@@ -212,14 +217,21 @@ __global__ __launch_bounds__(256, 4) void setup_kernel(FrameParams P) {
 #pragma unroll
     for (int half = 0; half < 2; half++) {
 #pragma unroll
-      for (int i = 0; i < 8; i++) sl[lane * 8u + ((uint32_t)i ^ (lane & 7u))] = piece[half * 8 + i];
+      for (uint32_t r = 0; r < 2u; r++) {  // records 32 r .. 32 r + 31
+        __builtin_amdgcn_wave_barrier();   // (the wave's LDS operations retire in order; this pins the compiler's order)
+        if ((lane >> 5) == r) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        uint32_t t = (uint32_t)k * 8u + (lane >> 3), i = lane & 7u;
-        uint4 v = sl[t * 8u + (i ^ (t & 7u))];
-        bool header = half == 0 && i == 0u;
-        if ((act >> t) & 1ull)
-          if (header || ((okm >> t) & 1ull)) wave_recs[t * 16u + (uint32_t)half * 8u + i] = v;
+          for (int i = 0; i < 8; i++) sl[(lane & 31u) * 8u + ((uint32_t)i ^ (lane & 7u))] = piece[half * 8 + i];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t tl = (uint32_t)k * 8u + (lane >> 3), i = lane & 7u, t = 32u * r + tl;
+          uint4 v = sl[tl * 8u + (i ^ (tl & 7u))];
+          bool header = half == 0 && i == 0u;
+          if ((act >> t) & 1ull)
+            if (header || ((okm >> t) & 1ull)) wave_recs[t * 16u + (uint32_t)half * 8u + i] = v;
+        }
       }
     }
   }

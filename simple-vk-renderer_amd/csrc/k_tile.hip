@@ -20,7 +20,7 @@
 //   phase C  transparent bin sorted by key in LDS, banded column scan (wave w owns rows 8w..8w+7) that
 //            appends depth-passing fragments to per-wave queues in submission order; the scan stops whenever a
 //            queue holds 64 fragments, they are shaded and blended at target precision, and the scan resumes from a
-//            (chunk, row) pair; bins over SORT_CAP (1408) entries sort in a global arena instead
+//            (chunk, row) pair; bins over SORT_CAP (1392) entries sort in a global arena instead
 //   phase D  write-back: whole tiles go out through LDS as full rows, the depth CLEAR and a deferred
 //            svr_clear_color are fused here
 // Heavy tiles of small passes are rendered as four 8-row quarters by four workgroups (tile_kernel<.., SPLIT>).
@@ -456,9 +456,9 @@ __device__ __forceinline__ uint32_t resolve_record(const FrameParams& P, uint32_
 // blended into the wave's LDS colour band.  Several fragments of one pixel can sit in the same group
 // of 64: the lowest lane of every pixel applies them in lane order = queue order (flush_fragments).
 // In a quarter of a split tile (svr_device.h SPLIT_*) a wave owns 2 rows instead of 8.
-constexpr uint32_t SORT_CAP = SPLIT_SORT_MAX;             // (1408) bins above this are sorted in the global sort arena instead of LDS
+constexpr uint32_t SORT_CAP = SPLIT_SORT_MAX;             // (1392) bins above this are sorted in the global sort arena instead of LDS
 constexpr uint32_t RANK_SORT_MAX = 1024;                  // bins up to this are ranked on their 32-bit keys (rank_sort), up to SORT_CAP by rank_sort_big
-constexpr uint32_t QUARTER_LIST_CAP = 3840;               // entries of a quarter's row-filtered opaque list (LDS behind the depth tile); bins are taken in windows of this
+constexpr uint32_t QUARTER_LIST_CAP = 3808;               // entries of a quarter's row-filtered opaque list (LDS behind the depth tile); bins are taken in windows of this
 constexpr uint32_t QUEUE_CAP = 128;                       // < 64 carried over + up to 64 new per row step
 
 template <int FMT, bool INSTR>
@@ -990,7 +990,8 @@ constexpr uint32_t LDS_Z_OFF = TILE * TILE * 8;
 constexpr uint32_t LDS_C_OFF = LDS_Z_OFF + TILE * TILE * 4;
 constexpr uint32_t WAVE_C_BYTES = QUEUE_CAP * 8 + 64 * 16;  // queue | shaded colours
 // the four waves' blocks, or the sort's scratch (keys + record indices of SORT_CAP entries) before the scan starts.
-// The workgroup's LDS — this + the 8 KiB staging buffer + a few words — stays under 32 KiB: five workgroups per CU.
+// The workgroup's LDS — this + the 8 KiB staging buffer + a few words — stays under 32 000 bytes (25 granules of 1280 B):
+// five workgroups per CU.
 constexpr uint32_t PHASE_C_BYTES = LDS_C_OFF + (SORT_CAP * 8 > 4 * WAVE_C_BYTES ? SORT_CAP * 8 : 4 * WAVE_C_BYTES);
 
 // The lane's pixel (rx, ry) in the tile and its word li in the tile's LDS images, made afresh from the thread index
@@ -1317,7 +1318,9 @@ __global__ __launch_bounds__(256, SVR_TILE_WAVES) void tile_kernel(FrameParams P
   static_assert(LDS_Z_OFF + QUARTER_LIST_CAP * 4 <= PHASE_C_BYTES, "depth tile + a quarter's triangle list");
   static_assert(SPLIT_SORT_MAX <= SORT_CAP && PHASE_C_BYTES - LDS_C_OFF >= SORT_CAP * 8 && PHASE_C_BYTES - LDS_C_OFF >= RANK_SORT_MAX * 8 &&
                     PHASE_C_BYTES - LDS_C_OFF >= 4 * WAVE_C_BYTES, "sort scratch aliases the waves' phase-C blocks");
-  static_assert(sizeof(s_cov) + sizeof(s_idx) + PHASE_C_BYTES + 64 <= 32768, "five workgroups per CU: 160 KiB of LDS");
+  // gfx950 hands out its 160 KiB of LDS in granules of 1280 bytes (320 dwords): five workgroups per CU need 25 granules
+  // each, 32 000 bytes — NOT 32 768 (at 32 064 bytes the kernel stayed at four per CU: tools/frames.py --wgtimes)
+  static_assert(sizeof(s_cov) + sizeof(s_idx) + PHASE_C_BYTES + 64 <= 25 * 1280, "five workgroups per CU: 25 LDS granules of 1280 B");
   static_assert(TILE * TILE * 8 >= TILE * TILE * sizeof(uint2), "the colour tile aliases the visibility tile");
 
   // Everything the workgroup needs before it can start comes in ONE round of scalar loads: the failure flags
@@ -1397,7 +1400,20 @@ void launch_tiles(const FrameParams& P, int color_format, bool count_fragments, 
 #else
   constexpr uint32_t lds_pad = 0u;
 #endif
-#define SVR_LAUNCH_TILES(FMT, INSTR, SPLIT) hipExtLaunchKernelGGL((tile_kernel<FMT, INSTR, SPLIT>), grid, block, lds_pad, s, start, tile_done, 0, P)
+  // Workgroups per CU.  Both instances fit five (<= 96 VGPRs, 25 of gfx950's 1280-byte LDS granules).  A pass of more
+  // than SPLIT_TILES_MAX tiles is tile-bound — stage 1 of the next pass has slack and takes the slots retiring workgroups
+  // free — and runs at five: 8K x16 1.512 -> 1.425 ms per frame.  Small passes — a 1080p frame, a rank's share of a
+  // sharded one — are bounded by STAGE 1: there a fifth tile workgroup per CU takes the room stage 1 of the next pass runs
+  // in (1080p 0.091 -> 0.100 ms, a rank of eight at 8K 0.367 -> 0.384), so their launches claim one LDS granule more and
+  // stay at four.  (A/B builds, tools/build_variant.sh: SVR_AB_TILE_PAD pads every launch, SVR_AB_NO_PAD none.)
+#if defined(SVR_AB_TILE_PAD)
+  const uint32_t pad = 1280u;
+#elif defined(SVR_AB_NO_PAD)
+  const uint32_t pad = 0u;
+#else
+  const uint32_t pad = P.n_tiles <= SPLIT_TILES_MAX ? 1280u : 0u;
+#endif
+#define SVR_LAUNCH_TILES(FMT, INSTR, SPLIT) hipExtLaunchKernelGGL((tile_kernel<FMT, INSTR, SPLIT>), grid, block, lds_pad + pad, s, start, tile_done, 0, P)
   if (color_format == SVR_COLOR_RGBA16F) {
     if (count_fragments) {
       if (split) SVR_LAUNCH_TILES(SVR_COLOR_RGBA16F, true, true);

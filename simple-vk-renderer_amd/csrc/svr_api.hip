@@ -435,7 +435,11 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   // the second ended up in ONE queue, 0.093 -> 0.27 ms per 1080p frame).
   hipStream_t s = ctx->stream, g = ctx->stream;
   if (pipe) {
+#ifdef SVR_AB_STAGE1_HI  // A/B builds only: stage 1 of every pass on the high-priority stream
+    const bool hi = true;
+#else
     const bool hi = P.n_tiles <= SPLIT_TILES_MAX;
+#endif
     hipStream_t& slot = hi ? ctx->gstream_hi : ctx->gstream;
     if (!slot) {
       if (hi) {

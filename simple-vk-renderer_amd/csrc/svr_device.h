@@ -52,7 +52,7 @@ constexpr uint32_t ROW_COST_MAX = 512;        // tile rows of the largest target
 #endif
 constexpr uint32_t TILE_SLOTS = SVR_AB_TILE_SLOTS;  // resident tile workgroups the split rule's mean load is taken over
 __host__ __device__ inline uint32_t tile_cost(uint32_t n_op, uint32_t n_tr) { return 40u + (n_op >> 3) + n_tr - (n_tr >> 2); }
-constexpr uint32_t SPLIT_SORT_MAX = 1408;      // quarters sort in LDS, out of place (k_tile.hip SORT_CAP): larger transparent bins stay whole
+constexpr uint32_t SPLIT_SORT_MAX = 1392;      // quarters sort in LDS, out of place (k_tile.hip SORT_CAP): larger transparent bins stay whole
 
 // One draw call (RenderObject after cull+sort), 192 bytes.  Read by the setup kernel through scalar loads
 // (the draw is wave-uniform): the whole record arrives in one round trip.
