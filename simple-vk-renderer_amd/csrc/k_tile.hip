@@ -37,6 +37,9 @@
 namespace svr {
 
 constexpr uint32_t REC_COMMON = 0x80000000u;  // in a lane's winning record index: the key's common-case bit (record indices stay below 2^31)
+#ifndef SVR_PRIO_COST
+#define SVR_PRIO_COST 200u  // tile_cost (thousands of cycles, svr_device.h) from which a tile's waves run at raised priority
+#endif
 constexpr int BATCH = 64;  // triangles staged per LDS batch == wave size: 64 x 128 B = 8 KiB
 
 // ------------------------------------------------------------------------------------------------
@@ -1038,6 +1041,13 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
     tile = i0.x; n_op = i0.y; off_op = i0.z; n_tr = i0.w; off_tr = i1.x; sort_base = i1.y; rows = i1.z; is_split = i1.w;
   }
   if (SPLIT && !QUARTER && is_split) return;  // a split tile's slot in the ordinary launch order: its quarters head the launch
+#ifndef SVR_AB_NO_PRIO
+  // The kernel lasts as long as its slowest tiles: the ones that see a curtain edge-on (hundreds of transparent triangles,
+  // ~35 layers: 36 000 fragments to shade on 1024 pixels, in order) start first and are still running when every other
+  // tile is done — all the longer the more workgroups share their SIMDs (five per CU: resident 167 us of the kernel's 168).
+  // Their waves ask for issue priority: what they take from the neighbours, the neighbours have to spare.
+  if (tile_cost(n_op, n_tr) >= SVR_PRIO_COST) __builtin_amdgcn_s_setprio(3);
+#endif
   // this workgroup's rows of the tile, row0 .. row0 + nrows - 1; pixels outside them are treated like pixels outside the scissor
   const int row0 = QUARTER ? (int)(rows & 0xffu) : 0;
   constexpr uint32_t lrpw = QUARTER ? 1u : 3u;  // log2(rows per wave in phase C)
