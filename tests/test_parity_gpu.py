@@ -321,6 +321,55 @@ def test_vertex_runs_of_every_length(hip, oracle):
         assert_same(frames[0], frames[1], f"triangles shuffled in windows of {window}")
 
 
+def test_draws_that_start_anywhere(hip, oracle):
+    """Wave chunks are cut along the mesh's index-group grid (64 triangles), not from a draw's first triangle: draws that
+    start one triangle into a group, one short of its end, exactly on it, that are shorter than a chunk or end mid-group —
+    and one whose first index is not a multiple of 3 (its triangles straddle the grid: the plain cut) — are the oracle's
+    frame, on the host path and with cull / sort / draw records / chunks made on the device."""
+    pkg = g.load_package()
+    S, A = pkg.scenes, pkg.abi
+    rng = np.random.default_rng(77)
+    # one mesh: a 40 x 40 grid of quads in front of the camera, z varying, 3200 triangles, vertices near their triangles
+    n = 40
+    xs, ys = np.meshgrid(np.linspace(-6, 6, n + 1), np.linspace(-3.5, 3.5, n + 1))
+    v = np.zeros((n + 1) * (n + 1), dtype=A.VERTEX_DTYPE)
+    v["position"][:, 0], v["position"][:, 1] = xs.ravel(), ys.ravel()
+    v["position"][:, 2] = -12.0 + rng.uniform(-1.5, 1.5, v.size)
+    v["normal"] = (0.0, 0.6, 0.8)
+    v["uv_x"], v["uv_y"] = (xs.ravel() + 6) / 3, (ys.ravel() + 3.5) / 3
+    v["color"] = rng.uniform(0.4, 1.0, (v.size, 4))
+    quads = np.arange(n * n)
+    a = quads // n * (n + 1) + quads % n
+    idx = np.stack([a, a + 1, a + n + 1, a + 1, a + n + 2, a + n + 1], axis=1).astype(np.uint32).reshape(-1)
+    draws = [(0, 1), (3 * 1, 62), (3 * 63, 1), (3 * 64, 64), (3 * 128, 65), (3 * 200, 300), (3 * 511, 130), (3 * 700 + 1, 100),
+             (3 * 1000, 1000), (3 * 2047, 2), (3 * 2100, 1100)]  # (first index, triangles)
+    for flatten in (2, 1):
+        frames = []
+        for lib in (hip, oracle):
+            r = lib.create(640, 360)
+            mesh = r.upload_mesh(idx, v)
+            img = r.create_image(S.make_texture(np.random.default_rng(5), 64, 0) if hasattr(S, "make_texture") else S.checkerboard_32(), mipmapped=True)
+            smp = r.create_sampler(**S.SAMPLER_TRILINEAR)
+            mats = [r.write_material(A.PASS_MAIN_COLOR, (1, 1, 1, 1), img, smp), r.write_material(A.PASS_TRANSPARENT, (0.3, 0.3, 0.3, 1), img, smp)]
+            objs = np.zeros(len(draws), dtype=A.RENDER_OBJECT_DTYPE)
+            for k, (first, tris) in enumerate(draws):
+                objs[k]["first_index"], objs[k]["index_count"], objs[k]["mesh"] = first, 3 * tris, mesh
+                objs[k]["material"] = mats[1] if k in (3, 8) else mats[0]
+                objs[k]["origin"], objs[k]["extents"], objs[k]["sphere_radius"] = (0, 0, -12), (6, 3.5, 1.5), 8.0
+                objs[k]["transform"] = np.eye(4, dtype=np.float32).reshape(16)
+            opaque = objs[[k for k in range(len(draws)) if k not in (3, 8)]]
+            transparent = objs[[3, 8]]
+            scene = S.scene_data_struct((0.0, 0.0, 0.0), 0.0, 0.0, 640, 360)
+            r.set_option(A.OPT_COUNT_FRAGMENTS, 1)
+            r.set_option(A.OPT_DEVICE_FLATTEN, flatten)
+            r.clear_color((1, 1, 1, 1))
+            r.draw_geometry(scene, opaque, transparent)
+            frames.append(T._finish(r))
+            r.close()
+        assert frames[1]["stats"].shaded_fragments > 20000
+        assert_same(frames[0], frames[1], f"draws that start anywhere (device flatten {flatten})", stats=False)
+
+
 def test_split_tiles_change_nothing(hip):
     """SVR_OPT_TUNING bit 3 keeps heavy tiles whole; the quarters of split tiles give the same frame.  (At this size
     the curtain tiles hold hundreds of transparent triangles and the pass's mean load per slot is small: they split.)"""

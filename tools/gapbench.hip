@@ -146,6 +146,29 @@ int main() {
                             : "two streams: pipeline, tile event by hipEventRecord",
              now_us() - t, 100.0, LINKS);
     }
+    // 5a. the pipeline of 5. with other event flags: no system-scope fence when the event is recorded / a device-scope release
+    for (int fl = 0; fl < 2; fl++) {
+      const unsigned flags = hipEventDisableTiming | (fl == 0 ? hipEventDisableSystemFence : hipEventReleaseToDevice);
+      std::vector<hipEvent_t> et(RING), eb(RING);
+      for (int i = 0; i < RING; i++) {
+        CHECK(hipEventCreateWithFlags(&et[i], flags));
+        CHECK(hipEventCreateWithFlags(&eb[i], flags));
+      }
+      CHECK(hipDeviceSynchronize());
+      t = now_us();
+      for (int i = 0; i < LINKS; i++) {
+        if (i >= 2) CHECK(hipStreamWaitEvent(g, et[(i - 2) % RING], 0));
+        hipExtLaunchKernelGGL(spin, dim3(256), block, 0, g, nullptr, eb[i % RING], 0, T_SHORT, nullptr);
+        CHECK(hipStreamWaitEvent(s, eb[i % RING], 0));
+        hipExtLaunchKernelGGL(spin, grid, block, 0, s, nullptr, et[i % RING], 0, T_LONG, nullptr);
+      }
+      CHECK(hipDeviceSynchronize());
+      report(fl == 0 ? "two streams: pipeline, events with hipEventDisableSystemFence" : "two streams: pipeline, events with hipEventReleaseToDevice", now_us() - t, 100.0, LINKS);
+      for (int i = 0; i < RING; i++) {
+        CHECK(hipEventDestroy(et[i]));
+        CHECK(hipEventDestroy(eb[i]));
+      }
+    }
     // 5b. the tile kernel's wait as a stream memory operation on a device word / as a one-wave gate kernel
     {
       static unsigned int* flag = nullptr;
