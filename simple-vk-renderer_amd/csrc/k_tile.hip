@@ -125,15 +125,18 @@ __device__ __forceinline__ float interp3(float a0, float da1, float da2, float b
   return fmaf(b2, da2, fmaf(b1, da1, a0)) * r;
 }
 
-// (Tried and dropped, both bit-exact: taking the quad partners' u,v from lanes ^1 / ^8 by DPP when a
-// whole 8x8 block runs whole quads of one triangle — with ~40 triangles per tile almost no block
-// qualifies, -1 %; the 4-pixel loop is VALU-issue-bound at ~500 instructions per pixel, SQ counters
-// in DESIGN.md.)
+// The quad partners' u,v by DPP: lanes ^1 / ^8 of an 8x8 block hold the pixel's horizontal / vertical quad partner.
+// Where every quad of the block is of one triangle (QUADS, wave-uniform: 42 % of a 4K frame's pixels, 77 % of the 8K x16
+// frame's) the partner's own u,v ARE the values this lane would extrapolate for it — the edge functions are exact
+// integers either way, the rest is the same chain on the same record — and two barycentric pairs, two reciprocals
+// and four attribute interpolations per pixel are not computed.
+__device__ __forceinline__ float quad_partner_x(float v) { return u2f((uint32_t)__builtin_amdgcn_mov_dpp((int)f2u(v), 0xB1, 0xf, 0xf, true)); }   // quad_perm:[1,0,3,2]
+__device__ __forceinline__ float quad_partner_y(float v) { return u2f((uint32_t)__builtin_amdgcn_mov_dpp((int)f2u(v), 0x128, 0xf, 0xf, true)); }  // row_ror:8
 // COMMON: the caller knows (key bit 1) that this is mesh.frag with a LINEAR/LINEAR/MIPMAP_LINEAR sampler
 // on an image with power-of-two extents:
 // pipeline kind, filter and mip-mode selections fold away (same arithmetic on the surviving path).
 template <bool TRACE, bool COMMON = false>
-__device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec, int px, int py, float* trace) {
+__device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec, int px, int py, float* trace, const bool quads = false) {
   const TriRec* tr = P.recs + rec;
   const uint4* q4 = reinterpret_cast<const uint4*>(tr);
   const float4* f4 = reinterpret_cast<const float4*>(tr);
@@ -167,12 +170,16 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
   // e1,e2: unbiased edge values at the pixel; its horizontal / vertical quad partners are +-A, +-B away
   float b1 = (float)e1 * inv_area, b2 = (float)e2 * inv_area;
   float q0 = s0.x, dq1 = s0.y, dq2 = s0.z;
-  double sxp = (px & 1) ? -1.0 : 1.0, syp = (py & 1) ? -1.0 : 1.0;
-  float hb1 = (float)fma(sxp, A1, e1) * inv_area, hb2 = (float)fma(sxp, A2, e2) * inv_area;
-  float vb1 = (float)fma(syp, B1, e1) * inv_area, vb2 = (float)fma(syp, B2, e2) * inv_area;
-  const float qq = fmaf(b2, dq2, fmaf(b1, dq1, q0)), hq = fmaf(hb2, dq2, fmaf(hb1, dq1, q0)), vq = fmaf(vb2, dq2, fmaf(vb1, dq1, q0));
-  float r, hr, vr;
-  if (COMMON) {
+  const float qq = fmaf(b2, dq2, fmaf(b1, dq1, q0));
+  float hb1 = 0.0f, hb2 = 0.0f, vb1 = 0.0f, vb2 = 0.0f, hq = 1.0f, vq = 1.0f;
+  if (!quads) {
+    double sxp = (px & 1) ? -1.0 : 1.0, syp = (py & 1) ? -1.0 : 1.0;
+    hb1 = (float)fma(sxp, A1, e1) * inv_area, hb2 = (float)fma(sxp, A2, e2) * inv_area;
+    vb1 = (float)fma(syp, B1, e1) * inv_area, vb2 = (float)fma(syp, B2, e2) * inv_area;
+    hq = fmaf(hb2, dq2, fmaf(hb1, dq1, q0)), vq = fmaf(vb2, dq2, fmaf(vb1, dq1, q0));
+  }
+  float r, hr = 0.0f, vr = 0.0f;
+  if (COMMON && !quads) {
     rcp3_ieee(qq, hq, vq, r, hr, vr);  // one exponent-window test for the three
   } else {
     r = rcp_ieee(qq);
@@ -187,8 +194,14 @@ __device__ __forceinline__ float4 shade_pixel(const FrameParams& P, uint32_t rec
     hr = rcp_ieee(hq);
     vr = rcp_ieee(vq);
   }
-  float uh = interp3(s2.y, s4.y, s6.y, hb1, hb2, hr), vh = interp3(s2.z, s4.z, s6.z, hb1, hb2, hr);
-  float uv_ = interp3(s2.y, s4.y, s6.y, vb1, vb2, vr), vv_ = interp3(s2.z, s4.z, s6.z, vb1, vb2, vr);
+  float uh, vh, uv_, vv_;
+  if (quads) {
+    uh = quad_partner_x(u), vh = quad_partner_x(v);
+    uv_ = quad_partner_y(u), vv_ = quad_partner_y(v);
+  } else {
+    uh = interp3(s2.y, s4.y, s6.y, hb1, hb2, hr), vh = interp3(s2.z, s4.z, s6.z, hb1, hb2, hr);
+    uv_ = interp3(s2.y, s4.y, s6.y, vb1, vb2, vr), vv_ = interp3(s2.z, s4.z, s6.z, vb1, vb2, vr);
+  }
   float dudx = (px & 1) ? (u - uh) : (uh - u);
   float dvdx = (px & 1) ? (v - vh) : (vh - v);
   float dudy = (py & 1) ? (u - uv_) : (uv_ - u);
@@ -1181,8 +1194,11 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
     const int qx = (int)(((tid >> 6) & 1u) * 16u + (tid & 7u)) + (k & 1) * 8, qy = (int)((tid >> 7) * 16u + ((tid >> 3) & 7u)) + (k >> 1) * 8;
     const int px = tx0 + qx, py = ty0 + qy;
     if (__all(!dirty[k] || (recs[k] & REC_COMMON))) {
+      // every quad of this 8x8 block of one triangle (or empty): lane ^ 1 is the pixel to the left or right, lane ^ 8 above or below
+      const int rk = (int)recs[k];
+      const bool quads = __all(!dirty[k] || (__builtin_amdgcn_mov_dpp(rk, 0xB1, 0xf, 0xf, true) == rk && __builtin_amdgcn_mov_dpp(rk, 0x128, 0xf, 0xf, true) == rk));
       if (dirty[k]) {
-        lc[(uint32_t)qy * TILE + (uint32_t)qx] = CD::encode(shade_pixel<false, true>(P, recs[k] & ~REC_COMMON, px, py, nullptr));
+        lc[(uint32_t)qy * TILE + (uint32_t)qx] = CD::encode(shade_pixel<false, true>(P, recs[k] & ~REC_COMMON, px, py, nullptr, quads));
         if (INSTR) {
           n_shaded++;
           if (P.trace_buf && px == P.trace_x && py == P.trace_y) (void)shade_pixel<true>(P, recs[k] & ~REC_COMMON, px, py, P.trace_buf);
