@@ -287,9 +287,13 @@ class ShardedFrame:
             parts = [(flat[g * self.world * chunk:(g + 1) * self.world * chunk],
                       flat[(g * self.world + self.rank) * chunk:(g * self.world + self.rank + 1) * chunk]) for g in range(groups)]
             if self.on_gpu and dist.get_backend() == "nccl":
-                with dist._coalescing_manager(device=self.image_t.device, async_ops=async_op) as cm:
+                # (no `device=`: the manager documents that argument for backends WITHOUT a coalesced all-gather; RCCL has
+                # one, and the handle waited on below should be that operation's own)
+                with dist._coalescing_manager(async_ops=async_op) as cm:
                     for out, mine in parts:
                         dist.all_gather_into_tensor(out, mine)
+                if async_op and not cm.works:
+                    raise RuntimeError("the coalesced all-gather of the interleaved rows returned no handle to wait on")
                 return [cm] if async_op else None
             works = [dist.all_gather_into_tensor(out, mine, async_op=async_op) for out, mine in parts]
             return works if async_op else None
