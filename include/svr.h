@@ -118,7 +118,8 @@ typedef struct SvrStats {
   uint32_t culled_draws;         /* opaque draws rejected by is_visible */
   uint32_t timed_passes;         /* passes averaged into the three *_ms fields below */
   uint64_t shaded_fragments;     /* fragment-shader evaluations (no helper lanes) */
-  uint64_t rasterized_fragments; /* covered pixel-centre samples that reached the depth test */
+  uint64_t rasterized_fragments; /* covered pixel-centre samples that reached the depth test (of every triangle: what a forward
+                                  * rasteriser walks; uninstrumented passes may skip hidden triangles, SVR_OPT_TUNING bits 5/6) */
   uint64_t binned_triangles;     /* triangles that survived clip/cull/zero-area */
   uint64_t bin_entries;          /* (triangle, tile) pairs; like the three counters above: of the last
                                   * pass run with SVR_OPT_COUNT_FRAGMENTS (uninstrumented passes report nothing) */
@@ -289,6 +290,11 @@ int svr_run_vertex_shader(SvrContext* ctx, int shader, SvrMesh mesh, uint32_t fi
  * the next pass.  bit3: heavy tiles are rendered by one workgroup instead of four row quarters.  bit4: finished passes are
  * looked at by fences only (svr_sync, read-backs, svr_get_stats), not in passing by other calls: a queue overflow
  * (SVR_OPT_QUEUE_CAPS) is then always found late — what the tests of the replay behind an exchange need.
+ * bit5: the tile kernel's visibility phase walks every triangle; bit6: it runs its hierarchical depth test (triangles
+ * that cannot win in any 8x8 block they reach are dropped before they are walked) in every pass.  With neither bit the
+ * library chooses per pass: the test runs where bins are deep (96 entries per tile on average).  Passes run with
+ * SVR_OPT_COUNT_FRAGMENTS drop nothing — rasterized_fragments stays every covered sample, as the forward rasteriser
+ * counts them — and check the test instead: a dropped triangle's fragment that wins fails the pass (SVR_ERR_DEVICE).
  * SVR_OPT_DEVICE_FLATTEN: where svr_draw_geometry's host half runs — is_visible, the sort and the
  * per-object draw records (src/vk_engine.cpp:1361-1378, 1412-1457).  0 (default): on the device from
  * 2048 objects up, on the host below; 1: always on the device; 2: always on the host.  Same frames

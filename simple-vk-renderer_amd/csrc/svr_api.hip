@@ -639,6 +639,7 @@ int recover_from_overflow(SvrContext* ctx) {
       return fail(SVR_ERR_OVERFLOW, "a pass kept overflowing its internal queues after 12 replays");
     }
     if (op.P.instrument) note_pass_stats(ctx, op.P, c);
+    if (op.P.instrument && c.hiz_bad) return fail(SVR_ERR_DEVICE, "internal check failed: the hierarchical depth test dropped a fragment that wins (" + std::to_string(c.hiz_bad) + ")");
     if (op.P.flatten) note_flatten_stats(ctx, c);
     note_row_costs(ctx, op.P, op.slot);
     ctx->replayed++;
@@ -685,6 +686,11 @@ int retire_ops(SvrContext* ctx, bool blocking) {
       }
     }
     if (ctx->log[k].P.instrument) note_pass_stats(ctx, ctx->log[k].P, ctx->h_counters[slot]);
+    if (ctx->log[k].P.instrument && ctx->h_counters[slot].hiz_bad) {
+      const uint32_t bad = ctx->h_counters[slot].hiz_bad;
+      ctx->log.erase(ctx->log.begin(), ctx->log.begin() + (long)k + 1);
+      return fail(SVR_ERR_DEVICE, "internal check failed: the hierarchical depth test dropped a fragment that wins (" + std::to_string(bad) + ")");
+    }
     if (ctx->log[k].P.flatten) note_flatten_stats(ctx, ctx->h_counters[slot]);
     note_row_costs(ctx, ctx->log[k].P, slot);
     ctx->log.erase(ctx->log.begin(), ctx->log.begin() + (long)k + 1);

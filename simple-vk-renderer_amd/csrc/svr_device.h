@@ -31,6 +31,8 @@ constexpr uint32_t TUNE_NO_TILE_ORDER = 1u;   // tile kernel walks tiles row-maj
 constexpr uint32_t TUNE_NO_LAZY_CLEAR = 4u;   // svr_clear_color runs its own kernel at once instead of riding in the next pass
 constexpr uint32_t TUNE_NO_PIPELINE = 2u;     // geometry+binning on the caller's stream too (no overlap between passes)
 constexpr uint32_t TUNE_NO_SPLIT = 8u;        // heavy tiles are not cut into four row quarters
+constexpr uint32_t TUNE_HIZ = 64u;            // ... with it whatever the pass's bins hold (tests; the default is a choice per pass: k_tile.hip HIZ_AVG_ENTRIES)
+constexpr uint32_t TUNE_NO_HIZ = 32u;         // phase A of the tile kernel walks every triangle (no hierarchical depth test)
 constexpr uint32_t TUNE_NO_POLL = 16u;        // finished passes are validated at fences only (tests: an overflow is always found late)
 
 // A heavy tile is rendered by FOUR workgroups, one per 8 rows (tile kernel "quarters").  The slowest tile
@@ -172,7 +174,9 @@ struct Counters {
   uint32_t flat_tris;      // their triangles
   uint32_t flat_chunks;    // their wave chunks: the setup kernel's real grid
   uint32_t flat_culled;    // opaque objects rejected by is_visible
-  unsigned long long pad2[2];  // 96 bytes: the counters head the tile-counter allocation (zeroed by the prologue)
+  uint32_t hiz_bad;        // instrumented passes: fragments the hierarchical depth test would have dropped although they win (must stay 0)
+  uint32_t pad1;
+  unsigned long long pad2;  // 96 bytes: the counters head the tile-counter allocation (zeroed by the prologue)
 };
 static_assert(sizeof(Counters) == 96, "Counters layout");
 

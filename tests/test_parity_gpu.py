@@ -381,6 +381,27 @@ def test_split_tiles_change_nothing(hip):
     assert np.array_equal(c["color"], d["color"]) and np.array_equal(c["depth"], d["depth"])
 
 
+def test_hierarchical_depth_test_changes_nothing(hip, oracle):
+    """Phase A's hierarchical depth test (k_tile.hip scan_columns + the deep bins' filter) drops triangles that cannot
+    win anywhere they reach.  SVR_OPT_TUNING bit 6 forces it whatever the pass's bins hold, bit 5 forbids it.
+    Uninstrumented passes really drop (the frame must be the oracle's); instrumented ones walk everything — their
+    fragment counts are the oracle's — and check every fragment of a triangle the test would have dropped: one that
+    wins fails the pass (svr_get_stats raises)."""
+    inst, cam5 = S.config5_instances(), S.config5_camera()
+    cases = [dict(width=960, height=540, lod=1, tex_size=64),                                    # whole tiles and quarters, bins to ~3000
+             dict(width=960, height=540, lod=1, tex_size=64, camera=((2.5, 1.0, -5.5), 0.2, 1.0)),   # inside a column: clipped pieces
+             dict(width=1280, height=720, lod=2, tex_size=32, camera=cam5, instances=inst),      # 16 interpenetrating instances: deep bins, the filter's windows
+             dict(width=333, height=187, lod=2, tex_size=64, scissor=(16, 8, 300, 170))]          # tiles cut by the scissor
+    for kw in cases:
+        ref = T.render_sponza(oracle, instrument=True, threads=16, **kw)
+        for tuning in (64, 32):
+            a = T.render_sponza(hip, instrument=True, tuning=tuning, **kw)   # counts + the self-check
+            assert_same(a, ref, f"hierarchical depth test, tuning {tuning}, instrumented, {kw}")
+            b = T.render_sponza(hip, tuning=tuning, **kw)                    # the kernel that drops
+            for key in ("color", "depth", "rgba8"):
+                T.assert_images_identical(b[key], ref[key], f"hierarchical depth test, tuning {tuning}, {key}, {kw}")
+
+
 def test_config5_instanced_reduced(hip, oracle):
     inst = S.config5_instances()
     cam = S.config5_camera()
