@@ -327,6 +327,9 @@ def main():
             "shaded_fragments_per_frame": shaded, "rasterized_fragments_per_frame": rasterized,
             "rasterized_fragments_per_s": rasterized * fps,
             "rasterized_per_shaded": rasterized / max(shaded, 1),
+            "rasterized_definition": "covered samples of every submitted triangle that reached the depth test, as a forward rasteriser walks them "
+                                     "(counted by the untimed instrumented frame, equal to the oracle's count); timed passes whose bins are deep "
+                                     "skip triangles hidden behind what their tile already holds (hierarchical depth test; not in this workload's 4K frame)",
             "binned_triangles": binned, "bin_entries": entries,
             "kernel_ms": {"tile": st.tile_ms, "passes": st.timed_passes},
             "roofline": {"bound": "hbm", "kernel": "tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
