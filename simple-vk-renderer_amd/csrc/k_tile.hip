@@ -490,14 +490,8 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
       double f1 = fma(c2.y, dx, fma(B1, dy, c5.y));
       double f2 = fma(c3.x, dx, fma(B2, dy, c6.x));
       unsigned long long* cell = s_depth + (y0 - ty0) * TILE + (col - tx0);
-#ifdef SVR_DEBUG_ROWS
-      int dbg_first = 1 << 20, dbg_last = -1;
-#endif
       for (int y = y0; y <= y1; y++) {
         if (f0 >= 0.0 && f1 >= 0.0 && f2 >= 0.0) {
-#ifdef SVR_DEBUG_ROWS
-          dbg_first = min(dbg_first, y); dbg_last = max(dbg_last, y);
-#endif
           if (INSTR) n_raster++;
           float b1 = (float)(f1 + u1) * zr.w, b2 = (float)(f2 + u2) * zr.w;
           float z = fmaf(b2, zr.z, fmaf(b1, zr.y, zr.x));
@@ -510,14 +504,6 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
         f2 += B2;
         cell += TILE;
       }
-#ifdef SVR_DEBUG_ROWS
-      if (INSTR) {  // lane-slots the walk used against what a walk over the covered span alone would use
-        int rows = y1 - y0 + 1, span = dbg_last >= dbg_first ? dbg_last - dbg_first + 1 : 0;
-        atomicAdd(&P.counters->pad1, (uint32_t)rows);
-        atomicAdd(reinterpret_cast<uint32_t*>(&P.counters->pad2), (uint32_t)span);
-        atomicAdd(reinterpret_cast<uint32_t*>(&P.counters->pad2) + 1, 1u);
-      }
-#endif
     }
   }
 }

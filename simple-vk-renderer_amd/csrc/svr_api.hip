@@ -555,9 +555,6 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
 }
 
 void note_pass_stats(SvrContext* ctx, const FrameParams&, const Counters& c) {  // instrumented passes only
-#ifdef SVR_DEBUG_ROWS
-  fprintf(stderr, "rows: %u items, %u rows walked, %u rows in covered spans; rasterized %llu\n", (uint32_t)(c.pad2 >> 32), c.pad1, (uint32_t)c.pad2, (unsigned long long)c.rasterized);
-#endif
   ctx->stats.bin_entries = c.total_entries;
   ctx->stats.rasterized_fragments = c.rasterized;
   ctx->stats.shaded_fragments = c.shaded;
