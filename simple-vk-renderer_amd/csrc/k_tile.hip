@@ -40,7 +40,12 @@ constexpr uint32_t REC_COMMON = 0x80000000u;  // in a lane's winning record inde
 #ifndef SVR_PRIO_COST
 #define SVR_PRIO_COST 200u  // tile_cost (thousands of cycles, svr_device.h) from which a tile's waves run at raised priority
 #endif
-constexpr int BATCH = 64;  // triangles staged per LDS batch == wave size: 64 x 128 B = 8 KiB
+constexpr int BATCH = 64;  // triangles staged per LDS batch == wave size
+// A staged record is the SEVEN 16-byte pieces the scans read (box/key/flags, depth plane, nine edge coefficients), 112
+// bytes apart: at the records' own 128 bytes every lane that reads the same piece of a different record falls on the
+// same four LDS banks (a sliver-rich batch: twenty-way conflicts on each of the seven reads per work item; the tile
+// kernel spent 8.0 M of its 18.6 M LDS cycles per launch on bank conflicts); at 112 eight records tile the 32 banks.
+constexpr uint32_t SREC = 7;  // pieces (uint4) per staged record
 
 // ------------------------------------------------------------------------------------------------
 // texture unit (C8, C9)
@@ -355,8 +360,9 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
   uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0;
   {
     uint32_t cnt = min((uint32_t)BATCH, n);
-    if (threadIdx.x < cnt * 8u) pre0 = reinterpret_cast<const uint4*>(P.recs + entry(threadIdx.x >> 3))[threadIdx.x & 7u];
-    if (threadIdx.x + 256u < cnt * 8u) pre1 = reinterpret_cast<const uint4*>(P.recs + entry(32u + (threadIdx.x >> 3)))[threadIdx.x & 7u];
+    const bool staged = (threadIdx.x & 7u) < SREC;  // (the eighth piece — texture words — is not staged: SREC)
+    if (staged && threadIdx.x < cnt * 8u) pre0 = reinterpret_cast<const uint4*>(P.recs + entry(threadIdx.x >> 3))[threadIdx.x & 7u];
+    if (staged && threadIdx.x + 256u < cnt * 8u) pre1 = reinterpret_cast<const uint4*>(P.recs + entry(32u + (threadIdx.x >> 3)))[threadIdx.x & 7u];
   }
   // HIZ — the hierarchical depth test, a choice per pass (tile_kernel: passes whose bins are deep).  Visibility is a
   // maximum over (depth, key), so a triangle whose largest possible depth lies below what EVERY pixel of an 8x8 block
@@ -395,21 +401,22 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
       atomicMin(&s_bm[cur * 16u + b], min(min(lo.y, lo.w), min(hi.y, hi.w)));  // LDS
       if (threadIdx.x < 16u) s_bm[(cur ^ 1u) * 16u + threadIdx.x] = 0xffffffffu;
     }
-    if (threadIdx.x < cnt * 8u) s_cov[threadIdx.x] = pre0;
-    if (threadIdx.x + 256u < cnt * 8u) s_cov[threadIdx.x + 256u] = pre1;
+    if (threadIdx.x < cnt * 8u && (threadIdx.x & 7u) < SREC) s_cov[(threadIdx.x >> 3) * SREC + (threadIdx.x & 7u)] = pre0;
+    if (threadIdx.x + 256u < cnt * 8u && (threadIdx.x & 7u) < SREC) s_cov[(32u + (threadIdx.x >> 3)) * SREC + (threadIdx.x & 7u)] = pre1;
     __syncthreads();
     const uint4* bm4 = reinterpret_cast<const uint4*>(s_bm + cur * 16u);
     if (b0 + BATCH < n) {
       uint32_t nb = b0 + BATCH, ncnt = min((uint32_t)BATCH, n - nb);
-      if (threadIdx.x < ncnt * 8u) pre0 = reinterpret_cast<const uint4*>(P.recs + entry(nb + (threadIdx.x >> 3)))[threadIdx.x & 7u];
-      if (threadIdx.x + 256u < ncnt * 8u) pre1 = reinterpret_cast<const uint4*>(P.recs + entry(nb + 32u + (threadIdx.x >> 3)))[threadIdx.x & 7u];
+      const bool staged = (threadIdx.x & 7u) < SREC;
+      if (staged && threadIdx.x < ncnt * 8u) pre0 = reinterpret_cast<const uint4*>(P.recs + entry(nb + (threadIdx.x >> 3)))[threadIdx.x & 7u];
+      if (staged && threadIdx.x + 256u < ncnt * 8u) pre1 = reinterpret_cast<const uint4*>(P.recs + entry(nb + 32u + (threadIdx.x >> 3)))[threadIdx.x & 7u];
     }
     // lane i: column count of triangle i inside this tile
     int cx0 = 0, cw = 0;
     bool hidden = false;
     uint32_t gone = 0;  // columns of this lane's triangle the test takes out
     if (lane < cnt) {
-      uint4 h = s_cov[lane * 8u];
+      uint4 h = s_cov[lane * SREC];
       int minx = (int)(int16_t)(h.x & 0xffffu), miny = (int)(int16_t)(h.x >> 16);
       int maxx = (int)(int16_t)(h.y & 0xffffu), maxy = (int)(int16_t)(h.y >> 16);
       cx0 = max(minx, tx0);
@@ -417,7 +424,7 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
       int cy0 = max(miny, ry0), cy1 = min(maxy, ry0 + nrows - 1);
       cw = (cx1 >= cx0 && cy1 >= cy0) ? cx1 - cx0 + 1 : 0;
       if (test && cw) {
-        const float4 zr = reinterpret_cast<const float4*>(s_cov)[lane * 8u + 1u];
+        const float4 zr = reinterpret_cast<const float4*>(s_cov)[lane * SREC + 1u];
         const float zmax = fmaxf(zr.x, fmaxf(zr.x + zr.y, zr.x + zr.z)) + (fabsf(zr.x) + fabsf(zr.y) + fabsf(zr.z)) * 0x1p-21f;
         const uint32_t zb = f2u(fmaxf(zmax, 0.0f));
         uint32_t m = 0xffffffffu;
@@ -433,8 +440,8 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
         if (hidden) gone = (uint32_t)cw;
         if (!INSTR && hidden) cw = 0;  // it can change nothing where it reaches: no work items
       }
-      if (INSTR && cw)  // the verdict (this test's or the filter's tag) for the items' check; piece 7 (texture words) is not read by the scan; every wave writes the same
-        reinterpret_cast<uint32_t*>(s_cov)[(lane * 8u + 7u) * 4u] = (hidden || (LIST && (s_list[b0 + lane] >> 31))) ? 1u : 0u;
+      if (INSTR && cw)  // the verdict (this test's or the filter's tag) for the items' check: bit 31 of the staged flags word; every wave writes the same
+        reinterpret_cast<uint32_t*>(s_cov)[lane * SREC * 4u + 3u] = (h.w & 0x7fffffffu) | ((hidden || (LIST && (s_list[b0 + lane] >> 31))) ? 0x80000000u : 0u);
     }
     if (test) {
       const uint32_t nh = (uint32_t)__popcll(__ballot(hidden));
@@ -474,7 +481,7 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
       uint32_t excl = __shfl(inc, (int)i) - (uint32_t)__shfl(cw, (int)i);
       int col = __shfl(cx0, (int)i) + (int)(j - excl);
       if (!act) continue;
-      const uint4* rec = s_cov + i * 8u;
+      const uint4* rec = s_cov + i * SREC;
       uint4 h = rec[0];
       int miny = (int)(int16_t)(h.x >> 16), maxy = (int)(int16_t)(h.y >> 16);
       int y0 = max(miny, ry0 + (int)band * band_rows), y1 = min(maxy, ry0 + (int)band * band_rows + band_rows - 1);
@@ -496,7 +503,7 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
           float b1 = (float)(f1 + u1) * zr.w, b2 = (float)(f2 + u2) * zr.w;
           float z = fmaf(b2, zr.z, fmaf(b1, zr.y, zr.x));
           z = fminf(fmaxf(z, 0.0f), 1.0f) + 0.0f;
-          if (INSTR && reinterpret_cast<const uint32_t*>(rec)[28] && f2u(z) >= (uint32_t)(*cell >> 32)) n_hiz_bad++;  // (cells only grow: no false alarm)
+          if (INSTR && (flags >> 31) && f2u(z) >= (uint32_t)(*cell >> 32)) n_hiz_bad++;  // (cells only grow: no false alarm)
           atomicMax(cell, ((unsigned long long)f2u(z) << 32) | key);
         }
         f0 += B0;  // exact: integers below 2^53
@@ -661,21 +668,21 @@ __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4
       if (t0 < cnt) ri0 = order[b0 + t0];
       if (t0 + 32u < cnt) ri1 = order[b0 + 32u + t0];
       uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
-      if (t0 < cnt) r0 = reinterpret_cast<const uint4*>(P.recs + ri0)[pc];
-      if (t0 + 32u < cnt) r1 = reinterpret_cast<const uint4*>(P.recs + ri1)[pc];
+      if (t0 < cnt && pc < SREC) r0 = reinterpret_cast<const uint4*>(P.recs + ri0)[pc];
+      if (t0 + 32u < cnt && pc < SREC) r1 = reinterpret_cast<const uint4*>(P.recs + ri1)[pc];
       if (t0 < cnt) {
-        s_cov[st] = r0;
+        if (pc < SREC) s_cov[t0 * SREC + pc] = r0;
         if (pc == 0) s_idx[t0] = ri0;
       }
       if (t0 + 32u < cnt) {
-        s_cov[st + 256u] = r1;
+        if (pc < SREC) s_cov[(t0 + 32u) * SREC + pc] = r1;
         if (pc == 0) s_idx[t0 + 32u] = ri1;
       }
     }
     __syncthreads();
     int cx0 = 0, cw = 0;
     if (lane < cnt) {
-      uint4 h = s_cov[lane * 8u];
+      uint4 h = s_cov[lane * SREC];
       int minx = (int)(int16_t)(h.x & 0xffffu), miny = (int)(int16_t)(h.x >> 16);
       int maxx = (int)(int16_t)(h.y & 0xffffu), maxy = (int)(int16_t)(h.y >> 16);
       cx0 = max(minx, tx0);
@@ -711,7 +718,7 @@ __device__ __forceinline__ void scan_columns_ordered(const FrameParams& P, uint4
         uint32_t excl = __shfl(inc, (int)i) - (uint32_t)__shfl(cw, (int)i);
         int colx = __shfl(cx0, (int)i) + (int)(j - excl) - tx0;  // column inside the tile
         colx = act ? colx : 0;
-        const uint4* rec = s_cov + i * 8u;
+        const uint4* rec = s_cov + i * SREC;
         uint4 h = rec[0];
         int y0 = (int)(int16_t)(h.x >> 16), y1 = (int)(int16_t)(h.y >> 16);
         uint32_t flags = h.w, ri = s_idx[i];
