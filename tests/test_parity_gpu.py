@@ -401,6 +401,20 @@ def test_hierarchical_depth_test_changes_nothing(hip, oracle):
             for key in ("color", "depth", "rgba8"):
                 T.assert_images_identical(b[key], ref[key], f"hierarchical depth test, tuning {tuning}, {key}, {kw}")
 
+    # a rank of the interleaved multi-GPU form (every third tile row, svr_set_row_interleave), RGBA8 target: with and without
+    frames = []
+    for tuning in (64, 32):
+        r, scene, opaque, transparent = T.setup_sponza(hip, 960, 540, lod=1, tex_size=64, color_format=1)
+        r.set_option(4, tuning)
+        r.set_row_interleave(3, 1)
+        r.clear_color((1, 1, 1, 1))
+        r.draw_geometry(scene, opaque, transparent)
+        r.sync()
+        frames.append((r.read_color(), r.read_depth()))
+        r.close()
+    T.assert_images_identical(frames[0][0], frames[1][0], "hierarchical depth test under a row interleave, colour")
+    T.assert_images_identical(frames[0][1], frames[1][1], "hierarchical depth test under a row interleave, depth")
+
 
 def test_config5_instanced_reduced(hip, oracle):
     inst = S.config5_instances()
