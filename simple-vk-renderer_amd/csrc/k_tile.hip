@@ -349,7 +349,7 @@ struct Codec<SVR_COLOR_RGBA8> {
 template <bool INSTR, bool LIST, bool HIZ>
 __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov, const uint32_t* s_list, uint32_t bin_base, uint32_t n,
                                              unsigned long long* s_depth, uint32_t* s_bm, int tx0, int ty0, int ry0, int nrows,
-                                             uint32_t& n_raster, uint32_t& n_hiz_bad) {
+                                             uint32_t& n_raster, uint32_t& n_hiz_bad, uint32_t& occl) {
   // rows [ry0, ry0 + nrows) of the tile at (tx0, ty0): the whole tile, or one quarter of a split tile
   auto entry = [&](uint32_t i) -> uint32_t { return LIST ? (s_list[i] & 0x7fffffffu) : P.bins[bin_base + i]; };  // (bit 31: tile_body's filter, instrumented passes)
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -415,18 +415,75 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
     int cx0 = 0, cw = 0;
     bool hidden = false;
     uint32_t gone = 0;  // columns of this lane's triangle the test takes out
+    uint32_t zb = 0, claim = 0;  // HIZ: the triangle's largest possible depth; an occluder's smallest over the rectangle (bits)
     if (lane < cnt) {
       uint4 h = s_cov[lane * SREC];
       int minx = (int)(int16_t)(h.x & 0xffffu), miny = (int)(int16_t)(h.x >> 16);
       int maxx = (int)(int16_t)(h.y & 0xffffu), maxy = (int)(int16_t)(h.y >> 16);
       cx0 = max(minx, tx0);
-      int cx1 = min(maxx, tx0 + TILE - 1);
-      int cy0 = max(miny, ry0), cy1 = min(maxy, ry0 + nrows - 1);
+      const int cx1 = min(maxx, tx0 + TILE - 1);
+      const int cy0 = max(miny, ry0), cy1 = min(maxy, ry0 + nrows - 1);
       cw = (cx1 >= cx0 && cy1 >= cy0) ? cx1 - cx0 + 1 : 0;
-      if (test && cw) {
+      if (HIZ && cw) {
         const float4 zr = reinterpret_cast<const float4*>(s_cov)[lane * SREC + 1u];
-        const float zmax = fmaxf(zr.x, fmaxf(zr.x + zr.y, zr.x + zr.z)) + (fabsf(zr.x) + fabsf(zr.y) + fabsf(zr.z)) * 0x1p-21f;
-        const uint32_t zb = f2u(fmaxf(zmax, 0.0f));
+        const float eps = (fabsf(zr.x) + fabsf(zr.y) + fabsf(zr.z)) * 0x1p-21f;
+        zb = f2u(fmaxf(fmaxf(zr.x, fmaxf(zr.x + zr.y, zr.x + zr.z)) + eps, 0.0f));  // the largest depth it can have anywhere
+        // An OCCLUDER: a triangle that covers every pixel of this workgroup's rows of the tile (a wall or a floor at this
+        // resolution covers many tiles) leaves every one of them at least as near as the smallest depth it has over the
+        // rectangle, whenever it is walked: whatever cannot reach that depth is hidden in the whole rectangle — also
+        // triangles of the same batch and of batches before it (visibility is a maximum: order does not matter).
+        // All three edges are >= 0 at the rectangle's four corner pixels (linear: the smallest of the four is C +
+        // min(A x0, A x1) + min(B y0, B y1), exact) and the triangle is convex; its depth over the rectangle is at
+        // least the plane's smallest corner value, through the same float chain as the walk, less the rounding bound.
+        if (minx <= tx0 && maxx >= tx0 + TILE - 1 && miny <= ry0 && maxy >= ry0 + nrows - 1) {
+          // (In FLOAT, with the rounding carried as margins — the edge values at the corners need not be exact for a
+          // claim that only has to be safe: in fp64, nine coefficients and four corners' chains were more live registers
+          // than the fragment stage's peak.  An edge value built from three terms of magnitude M is off by at most
+          // 3 * 2^-24 M: "inside" asks for 2^-21 M to spare, and the barycentrics' error, e / area, goes into the depth
+          // bound with the plane's slopes.)
+          const double* dd = reinterpret_cast<const double*>(s_cov + lane * SREC);  // [4..6] A0 A1 A2, [7..9] B0 B1 B2, [10..12] C0 C1 C2
+          const float x0 = (float)tx0, x1 = (float)(tx0 + TILE - 1), y0 = (float)ry0, y1 = (float)(ry0 + nrows - 1);
+          bool all_in = true;
+          float slack = 0.0f;  // what the float edge values may be off by, as a share of the area: the barycentrics' error
+          float bc[2][4];
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            const float A = (float)dd[4 + i], B = (float)dd[7 + i], C = (float)dd[10 + i] + ((i == 1 && (h.w & F_T1)) || (i == 2 && (h.w & F_T2)) ? 1.0f : 0.0f);
+            const float M = (fabsf(C) + fmaxf(fabsf(A * x0), fabsf(A * x1)) + fmaxf(fabsf(B * y0), fabsf(B * y1))) * 0x1p-21f;
+            const float e00 = fmaf(A, x0, fmaf(B, y0, C)), e10 = fmaf(A, x1, fmaf(B, y0, C));
+            const float e01 = fmaf(A, x0, fmaf(B, y1, C)), e11 = fmaf(A, x1, fmaf(B, y1, C));
+            all_in = all_in && fminf(fminf(e00, e10), fminf(e01, e11)) >= M + 1.0f;  // (+1: the bias of edges 1, 2 was added above; edge 0's is in C)
+            if (i) {
+              bc[i - 1][0] = e00 * zr.w; bc[i - 1][1] = e10 * zr.w; bc[i - 1][2] = e01 * zr.w; bc[i - 1][3] = e11 * zr.w;
+              slack = fmaxf(slack, M * zr.w);
+            }
+          }
+          if (all_in) {
+            float zmin = fmaf(bc[1][0], zr.z, fmaf(bc[0][0], zr.y, zr.x));
+            zmin = fminf(zmin, fmaf(bc[1][1], zr.z, fmaf(bc[0][1], zr.y, zr.x)));
+            zmin = fminf(zmin, fmaf(bc[1][2], zr.z, fmaf(bc[0][2], zr.y, zr.x)));
+            zmin = fminf(zmin, fmaf(bc[1][3], zr.z, fmaf(bc[0][3], zr.y, zr.x)));
+            zmin -= eps + 2.0f * slack * (fabsf(zr.y) + fabsf(zr.z));
+            claim = f2u(fminf(fmaxf(zmin, 0.0f), 1.0f));
+          }
+        }
+      }
+    }
+    if (HIZ) {  // the nearest occluder so far (wave-uniform, and the same in all four waves: same records)
+      unsigned long long claims = __ballot(claim != 0u);
+      while (claims) {
+        const int l = __ffsll((long long)claims) - 1;
+        claims &= claims - 1ull;
+        occl = max(occl, (uint32_t)__builtin_amdgcn_readlane((int)claim, l));
+      }
+      if (!INSTR && cw && zb < occl) cw = 0;  // hidden behind an occluder wherever it reaches
+    }
+    if (lane < cnt) {
+      if (test && cw) {  // the blocks it reaches, against what they hold (the box again from the staged header: kept in
+        // registers across the occluders' ballots it is what the allocator spills)
+        const uint4 h = s_cov[lane * SREC];
+        const int cx1 = min((int)(int16_t)(h.y & 0xffffu), tx0 + TILE - 1);
+        const int cy0 = max((int)(int16_t)(h.x >> 16), ry0), cy1 = min((int)(int16_t)(h.y >> 16), ry0 + nrows - 1);
         uint32_t m = 0xffffffffu;
         const int by0 = (cy0 - ty0) >> 3, by1 = (cy1 - ty0) >> 3;
         for (int bx = (cx0 - tx0) >> 3; bx <= (cx1 - tx0) >> 3; bx++) {
@@ -440,8 +497,10 @@ __device__ __forceinline__ void scan_columns(const FrameParams& P, uint4* s_cov,
         if (hidden) gone = (uint32_t)cw;
         if (!INSTR && hidden) cw = 0;  // it can change nothing where it reaches: no work items
       }
-      if (INSTR && cw)  // the verdict (this test's or the filter's tag) for the items' check: bit 31 of the staged flags word; every wave writes the same
-        reinterpret_cast<uint32_t*>(s_cov)[lane * SREC * 4u + 3u] = (h.w & 0x7fffffffu) | ((hidden || (LIST && (s_list[b0 + lane] >> 31))) ? 0x80000000u : 0u);
+      if (INSTR && cw) {  // the verdict (this test's or the filter's tag) for the items' check: bit 31 of the staged flags word; every wave writes the same
+        uint32_t* fl = reinterpret_cast<uint32_t*>(s_cov) + lane * SREC * 4u + 3u;
+        *fl = (*fl & 0x7fffffffu) | ((hidden || (LIST && (s_list[b0 + lane] >> 31))) ? 0x80000000u : 0u);
+      }
     }
     if (test) {
       const uint32_t nh = (uint32_t)__popcll(__ballot(hidden));
@@ -1166,6 +1225,7 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
     recs[k] = NO_REC;
   }
   uint32_t n_raster = 0, n_shaded = 0, n_hiz_bad = 0;
+  uint32_t occl = 0;  // scan_columns<HIZ>: depth bits every pixel of this workgroup's rows is claimed to reach (an occluder's smallest)
   long long stamp[5] = {0, 0, 0, 0, 0};  // SVR_OPT_TILE_CYCLES: shader-clock stamps per phase
   const bool stamps = P.tile_cycles != nullptr;
   if (stamps) stamp[0] = clock64();
@@ -1259,17 +1319,20 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
         }
         __syncthreads();
         const uint32_t n_mine = s_idx[0];
-        if (hiz_on) scan_columns<INSTR, true, true>(P, s_cov, s_list, 0u, n_mine, s_depth, s_idx + 16, tx0, ty0, sub_y0, nrows, n_raster, n_hiz_bad);
-        else scan_columns<INSTR, true, false>(P, s_cov, s_list, 0u, n_mine, s_depth, s_idx + 16, tx0, ty0, sub_y0, nrows, n_raster, n_hiz_bad);
+        if (hiz_on) scan_columns<INSTR, true, true>(P, s_cov, s_list, 0u, n_mine, s_depth, s_idx + 16, tx0, ty0, sub_y0, nrows, n_raster, n_hiz_bad, occl);
+        else scan_columns<INSTR, true, false>(P, s_cov, s_list, 0u, n_mine, s_depth, s_idx + 16, tx0, ty0, sub_y0, nrows, n_raster, n_hiz_bad, occl);
       }
     } else {
-      if (hiz_on) scan_columns<INSTR, false, true>(P, s_cov, nullptr, off_op, n_op, s_depth, s_idx + 16, tx0, ty0, QUARTER ? sub_y0 : ty0, nrows, n_raster, n_hiz_bad);
-      else scan_columns<INSTR, false, false>(P, s_cov, nullptr, off_op, n_op, s_depth, s_idx + 16, tx0, ty0, QUARTER ? sub_y0 : ty0, nrows, n_raster, n_hiz_bad);
+      if (hiz_on) scan_columns<INSTR, false, true>(P, s_cov, nullptr, off_op, n_op, s_depth, s_idx + 16, tx0, ty0, QUARTER ? sub_y0 : ty0, nrows, n_raster, n_hiz_bad, occl);
+      else scan_columns<INSTR, false, false>(P, s_cov, nullptr, off_op, n_op, s_depth, s_idx + 16, tx0, ty0, QUARTER ? sub_y0 : ty0, nrows, n_raster, n_hiz_bad, occl);
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; k++) {  // the winners' records move into the owning lanes' registers
       unsigned long long v = s_depth[li + (uint32_t)((k & 1) * 8 + (k >> 1) * 256)];
+      // (instrumented passes drop nothing: every pixel of the workgroup's rows must then have reached what the
+      // occluders of scan_columns claimed for it — the claim everything dropped behind them rests on)
+      if (INSTR && occl && (!QUARTER || (uint32_t)(ry + (k >> 1) * 8 - row0) < (uint32_t)nrows) && (uint32_t)(v >> 32) < occl) n_hiz_bad++;
       if ((uint32_t)v != 0u) {
         uint32_t main_slot = ((uint32_t)v >> 2) - 1u;
         uint32_t rec = ((uint32_t)v & 1u) ? resolve_record(P, main_slot, tx0 + rx + (k & 1) * 8, ty0 + ry + (k >> 1) * 8) : main_slot;
