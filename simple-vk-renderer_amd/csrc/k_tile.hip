@@ -1305,7 +1305,7 @@ __device__ __forceinline__ void tile_body(const FrameParams& P, const uint4 i0, 
                 m = min(m, (by0 <= 2 && by1 >= 2) ? q.z : 0xffffffffu);
                 m = min(m, (by0 <= 3 && by1 >= 3) ? q.w : 0xffffffffu);
               }
-              if (cx1 >= cx0 && zb < m) {
+              if (cx1 >= cx0 && (zb < m || zb < occl)) {  // (occl: the nearest occluder claim of the windows before, scan_columns)
                 if (INSTR) tag = 0x80000000u;
                 else keep = false;
               }
