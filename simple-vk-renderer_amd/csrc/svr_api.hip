@@ -468,7 +468,7 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
   size_t draw_bytes = (flat_op ? n_objects : draws.size()) * sizeof(DrawDesc), chunk_bytes = (size_t)P.n_chunks * sizeof(WaveChunk);
   if (int e = set.inputs.ensure(std::max<size_t>(draw_bytes + chunk_bytes + 16, 256))) return e;
   if (flat_op)
-    if (int e = set.flat.ensure(n_objects * 16 + 64)) return e;
+    if (int e = set.flat.ensure(n_objects * (16 + sizeof(SvrRenderObject)) + 128)) return e;
   if (int e = bind_pass_buffers(ctx, P, set_index)) return e;
   // How far stage 1 runs ahead.  A pass of few tiles (a band of a sharded frame: stage 1 56 us, tiles 50 us) is bounded
   // by stage 1, which then wants to run back to back: it only waits for its set, last read by the tile stage of
@@ -524,6 +524,7 @@ int submit_pass(SvrContext* ctx, FrameParams P, const std::vector<DrawDesc>& dra
     F.keys = (unsigned long long*)set.flat.p;
     F.draw_tris = (uint32_t*)((char*)set.flat.p + n_objects * 8);
     F.chunk_base = F.draw_tris + n_objects;
+    F.objects_dev = (SvrRenderObject*)((char*)set.flat.p + ((n_objects * 16 + 63) & ~(size_t)63));
     F.draws = (DrawDesc*)set.inputs.p;
     F.chunks = (WaveChunk*)((char*)set.inputs.p + draw_bytes);
     F.counters = P.counters;

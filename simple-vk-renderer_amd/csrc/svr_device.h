@@ -248,6 +248,7 @@ struct FrameParams {
 // k_flatten.hip: cull + sort + per-object draw records on the device
 struct FlattenParams {
   const SvrRenderObject* objects;  // pinned host memory: opaque list, then the transparent list
+  SvrRenderObject* objects_dev;    // the same, pulled into device memory by cull_kernel (coalesced, once) for the kernels behind it
   uint32_t n_opaque, n_transparent;
   float viewproj[16];
   const MeshEntry* meshes;
