@@ -215,30 +215,44 @@ __global__ __launch_bounds__(256, 4) void count_kernel(FrameParams P, uint32_t b
     if (threadIdx.x < 64u) clip_and_bin(P, s_clip, blockIdx.x - big_blocks, clip_blocks);
     return;
   }
-  const uint32_t lane = threadIdx.x & 63u;
-  const unsigned long long below = (1ull << lane) - 1ull;
+  // Which lanes of the wave target the same bin is found through a small LDS hash table of the wave's own (128
+  // entries for 64 pairs): a lane claims its bin's entry (compare-and-swap, linear probing), takes its rank from the
+  // entry's counter, and the lane that got rank 0 does the bin's ONE device atomic with the final count.  (The first
+  // version found the groups with a ballot per distinct bin: a wave of the 8K x16 frame's pairs — big triangles, every
+  // pair of a triangle a different tile — went round that loop dozens of times: 169 us for 6.6 M pairs.)
+  __shared__ uint32_t s_key[4][128], s_cnt[4][128], s_base[4][128];
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  uint32_t* hk = s_key[wv];
+  uint32_t* hc = s_cnt[wv];
+  uint32_t* hb = s_base[wv];
+  hk[lane] = 0u; hk[lane + 64u] = 0u;
+  hc[lane] = 0u; hc[lane + 64u] = 0u;
+  __builtin_amdgcn_wave_barrier();  // (LDS operations of a wave retire in order; this pins the compiler's order too)
   const uint32_t n = min(P.counters->n_pairs, P.bin_cap), rounded = (n + 63u) & ~63u;
   const uint32_t stride = (gridDim.x - rest_blocks) * blockDim.x;
   for (uint32_t i = (blockIdx.x - rest_blocks) * blockDim.x + threadIdx.x; i < rounded; i += stride) {
-    bool has = i < n;
-    uint32_t bin = has ? P.pairs[i].x : 0u;
-    unsigned long long todo = __ballot(has);
-    uint32_t leader = lane, rank = 0, cnt = 0;
-    while (todo) {
-      int l = __ffsll((long long)todo) - 1;
-      uint32_t b = __shfl(bin, l);
-      unsigned long long same = __ballot(has && bin == b);
-      if (has && bin == b) {
-        leader = (uint32_t)l;
-        rank = (uint32_t)__popcll(same & below);
-        cnt = (uint32_t)__popcll(same);
+    const bool has = i < n;
+    const uint32_t bin = has ? P.pairs[i].x : 0u;
+    uint32_t h = 0, rank = 1;
+    if (has) {
+      h = (bin * 0x9E3779B1u) >> 25;
+      for (;;) {
+        const uint32_t k = atomicCAS(&hk[h], 0u, bin + 1u);
+        if (k == 0u || k == bin + 1u) break;
+        h = (h + 1u) & 127u;
       }
-      todo &= ~same;
+      rank = atomicAdd(&hc[h], 1u);
     }
-    uint32_t base = 0;
-    if (has && leader == lane) base = atomicAdd(&P.tile_count[bin], cnt);
-    base = __shfl(base, (int)leader);
-    if (has) P.pair_slot[i] = base + rank;
+    __builtin_amdgcn_wave_barrier();
+    if (has && rank == 0u) hb[h] = atomicAdd(&P.tile_count[bin], hc[h]);  // (hc[h] is final: every lane's add of this round is behind it)
+    __builtin_amdgcn_wave_barrier();
+    if (has) P.pair_slot[i] = hb[h] + rank;
+    __builtin_amdgcn_wave_barrier();
+    if (has && rank == 0u) {
+      hk[h] = 0u;
+      hc[h] = 0u;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -371,6 +385,8 @@ __global__ __launch_bounds__(256) void fill_kernel(FrameParams P) {
 }
 
 void launch_bin_count(const FrameParams& P, hipStream_t s) {
+  // (128 blocks for the queued big triangles also in the 8K x16 frame: with 1024 the kernel is 246 us instead of 168 —
+  // what bounds it there is the device atomics on the bins' counters, and more waves only queue up behind them)
   const uint32_t big_blocks = 128, clip_blocks = 512;
   hipLaunchKernelGGL(count_kernel, dim3(big_blocks + clip_blocks + 1024u), dim3(256), 0, s, P, big_blocks, clip_blocks);
 }
