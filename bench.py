@@ -62,7 +62,7 @@ def parse():
                     help="N > 1: contiguous row bands, interleaved tile rows (t %% N == rank), or whichever a short trial of both finds faster")
     ap.add_argument("--cpu-frames", type=int, default=10)
     ap.add_argument("--blocks", type=int, default=25, help="repetitions of the timed --steps block (the median block is reported)")
-    ap.add_argument("--profile-tag", default="r03_g", help="profiles/<tag>_traffic.json and <tag>_valu.json of this build are quoted in the line")
+    ap.add_argument("--profile-tag", default="r03_h", help="profiles/<tag>_traffic.json and <tag>_valu.json of this build are quoted in the line")
     return ap.parse_args()
 
 

@@ -1,11 +1,11 @@
 #!/bin/bash
-# GPU box: everything profiles/<tag>_* is made from, for the build in the tree.   tools/profile_round.sh r03_g
+# GPU box: everything profiles/<tag>_* is made from, for the build in the tree.   tools/profile_round.sh r03_h
 #   <tag>_kernel_stats.csv   rocprofv3 --kernel-trace (per-kernel durations of bench.py's own command line)
 #   <tag>_pmc.txt            rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_*), one counter group per run, kernel trace only
 #   <tag>_traffic.json / <tag>_valu.json   what bench.py quotes in roofline.traffic / roofline_valu
 #   <tag>_solo_kernel_stats.csv            the same kernels with the two stages serialised (SVR_OPT_TUNING bit 1): solo durations
 #   <tag>_bench.json         the bench line itself (run last, unprofiled)
-tag=${1:-r03_g}
+tag=${1:-r03_h}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/$tag
 rm -rf $out; mkdir -p $out
