@@ -206,10 +206,15 @@ class ShardedFrame:
         self.swapchain = torch.zeros((hp, self.W, 4), dtype=torch.uint8, device=device) if present else None
         self.image_t = self.swapchain if present else self.color
         self.flat = self.image_t.view(-1)
+        # (addresses asked for once: tensor.data_ptr() per frame is host time of a 60-us frame)
+        self._color_ptr, self._depth_ptr = self.color.data_ptr(), self.depth.data_ptr()
+        self._swap_ptr = self.swapchain.data_ptr() if present else 0
         self.bound = bind
         self.work = None
         self._dist = None
         self._ops, self._ops_key = [], None
+        self._il_parts, self._eq_parts = None, None  # cached views of the image for the two all-gather forms
+        self._equal = equal_bounds(self.H, world)
         self.y0, self.rows = self.plan.rows_of(rank)
         self.bounds = list(self.plan.bounds)  # the partition this slot's frame in flight was rendered with
         self.partition = self.plan.partition
@@ -238,7 +243,7 @@ class ShardedFrame:
         self.bounds = list(self.plan.bounds)
         self.partition = self.plan.partition
         if self.bound:
-            self.r.bind_targets(self.color.data_ptr(), self.depth.data_ptr())
+            self.r.bind_targets(self._color_ptr, self._depth_ptr)
         if self.partition == "interleaved":
             self.y0, self.rows = 0, sum(n for _, n in interleaved_rows(self.H, self.rank, self.world))
             self._rows_state((0, 0, self.W, self.H), (self.world, self.rank))
@@ -281,11 +286,13 @@ class ShardedFrame:
         if self.partition == "interleaved":
             # tile row t belongs to rank t % world: every group of `world` consecutive tile rows is one in-place
             # all-gather of 32-row chunks (the buffers are padded to whole groups); RCCL: coalesced into one launch
-            chunk = 32 * self.W * self.image_t.shape[2] * self.image_t.element_size()
-            flat = self.image_t.view(self.torch.uint8).view(-1) if self.image_t.dtype != self.torch.uint8 else self.flat
-            groups = int(math.ceil(((self.H + 31) // 32) / self.world))
-            parts = [(flat[g * self.world * chunk:(g + 1) * self.world * chunk],
-                      flat[(g * self.world + self.rank) * chunk:(g * self.world + self.rank + 1) * chunk]) for g in range(groups)]
+            parts = self._il_parts
+            if parts is None:  # the views never change: made once (eighteen tensor slices per frame were 30-40 us of host time)
+                chunk = 32 * self.W * self.image_t.shape[2] * self.image_t.element_size()
+                flat = self.image_t.view(self.torch.uint8).view(-1) if self.image_t.dtype != self.torch.uint8 else self.flat
+                groups = int(math.ceil(((self.H + 31) // 32) / self.world))
+                parts = self._il_parts = [(flat[g * self.world * chunk:(g + 1) * self.world * chunk],
+                                           flat[(g * self.world + self.rank) * chunk:(g * self.world + self.rank + 1) * chunk]) for g in range(groups)]
             if self.on_gpu and dist.get_backend() == "nccl":
                 # (no `device=`: the manager documents that argument for backends WITHOUT a coalesced all-gather; RCCL has
                 # one, and the handle waited on below should be that operation's own)
@@ -297,10 +304,12 @@ class ShardedFrame:
                 return [cm] if async_op else None
             works = [dist.all_gather_into_tensor(out, mine, async_op=async_op) for out, mine in parts]
             return works if async_op else None
-        equal = self.bounds == equal_bounds(self.H, self.world)
+        equal = self.bounds == self._equal
         if equal:
-            n = self.band * self.W * 4
-            h = dist.all_gather_into_tensor(self.flat[:self.world * n], self.flat[self.rank * n:(self.rank + 1) * n], async_op=async_op)
+            if self._eq_parts is None:
+                n = self.band * self.W * 4
+                self._eq_parts = (self.flat[:self.world * n], self.flat[self.rank * n:(self.rank + 1) * n])
+            h = dist.all_gather_into_tensor(self._eq_parts[0], self._eq_parts[1], async_op=async_op)
             return h if async_op else None
         if self.image_t.is_cuda and dist.get_backend() == "gloo":
             # rehearsals on a one-GPU box (SVR_BENCH_REHEARSE): gloo moves device tensors only through its collectives,
@@ -342,7 +351,7 @@ class ShardedFrame:
             if self.rows > 0:  # vkutil::copy_image of this rank's rows (scissor / row set are still the frame's)
                 if self.verify == "frame":
                     self.r.set_present_status(self.status[self.rank:].data_ptr())
-                self.r.copy_to_swapchain(self.swapchain.data_ptr(), self.W, self.H, 0)
+                self.r.copy_to_swapchain(self._swap_ptr, self.W, self.H, 0)
                 if self.verify == "frame":
                     self.r.set_present_status(0)
         elif not self.bound:  # test path (CPU oracle owns its targets): copy the band out first
